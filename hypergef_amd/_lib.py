@@ -1,0 +1,112 @@
+"""ctypes binding of libhgaggr.so (the C ABI in include/hg_aggr.h).
+
+There is no fallback: if the shared library is missing or a call fails, the
+caller gets an exception.  Nothing here computes on the CPU.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhgaggr.so")
+
+HG_OK = 0
+HG_VARIANT_AUTO = 0
+HG_VARIANT_PULL = 1
+HG_VARIANT_PUSH_ATOMIC = 2
+HG_PLAN_HOST_ONLY = 1
+HG_PLAN_NO_XCD_REMAP = 2
+
+VARIANTS = {"auto": HG_VARIANT_AUTO, "pull": HG_VARIANT_PULL, "push_atomic": HG_VARIANT_PUSH_ATOMIC}
+
+# every symbol include/hg_aggr.h declares (tests check the library exports all)
+SYMBOLS = (
+    "hg_version", "hg_last_error", "hg_status_string", "hg_balance_schedule",
+    "hg_plan_create_host", "hg_plan_create_device", "hg_plan_destroy", "hg_plan_get_info",
+    "hg_plan_get_vertex_csr", "hg_plan_get_vertex_csr_device", "hg_plan_get_schedule",
+    "hg_plan_workspace_bytes",
+    "hg_aggr_fused_f32", "hg_gather_rows_f32", "hg_aggr_push_groups_f32",
+)
+
+
+class HgError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("libhgaggr: %s (status %d)" % (message, status))
+        self.status = status
+
+
+class PlanOpts(ctypes.Structure):
+    _fields_ = [("short_max", ctypes.c_int32), ("split_len", ctypes.c_int32),
+                ("panel_rows", ctypes.c_int32), ("panel_nnz", ctypes.c_int32),
+                ("flags", ctypes.c_int32)]
+
+
+class PlanInfo(ctypes.Structure):
+    _fields_ = [("N", ctypes.c_int32), ("M", ctypes.c_int32), ("nnz", ctypes.c_int64),
+                ("short_max", ctypes.c_int32), ("split_len", ctypes.c_int32),
+                ("panel_rows", ctypes.c_int32), ("panel_nnz", ctypes.c_int32),
+                ("flags", ctypes.c_int32),
+                ("panels", ctypes.c_int32 * 2), ("tasks", ctypes.c_int32 * 2),
+                ("partials", ctypes.c_int32 * 2), ("fixups", ctypes.c_int32 * 2),
+                ("max_len", ctypes.c_int32 * 2), ("device_bytes", ctypes.c_int64)]
+
+    def as_dict(self):
+        out = {}
+        for name, _ in self._fields_:
+            v = getattr(self, name)
+            out[name] = list(v) if hasattr(v, "__len__") else v
+        return out
+
+
+_lib = None
+
+
+def lib():
+    """Load libhgaggr.so once; raise if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C hypergef_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64, sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t
+    L.hg_version.restype = ctypes.c_int
+    L.hg_last_error.restype = ctypes.c_char_p
+    L.hg_status_string.restype = ctypes.c_char_p
+    L.hg_status_string.argtypes = [ctypes.c_int]
+    L.hg_balance_schedule.restype = ctypes.c_int
+    L.hg_balance_schedule.argtypes = [i32, i32, vp, ctypes.POINTER(i64), ctypes.POINTER(i64),
+                                      vp, vp, vp, vp]
+    L.hg_plan_create_host.restype = ctypes.c_int
+    L.hg_plan_create_host.argtypes = [ctypes.POINTER(vp), i32, i32, vp, vp, ctypes.POINTER(PlanOpts)]
+    L.hg_plan_create_device.restype = ctypes.c_int
+    L.hg_plan_create_device.argtypes = [ctypes.POINTER(vp), i32, i32, i64, vp, vp,
+                                        ctypes.POINTER(PlanOpts), vp]
+    L.hg_plan_destroy.restype = None
+    L.hg_plan_destroy.argtypes = [vp]
+    L.hg_plan_get_info.restype = ctypes.c_int
+    L.hg_plan_get_info.argtypes = [vp, ctypes.POINTER(PlanInfo)]
+    L.hg_plan_get_vertex_csr.restype = ctypes.c_int
+    L.hg_plan_get_vertex_csr.argtypes = [vp, vp, vp]
+    L.hg_plan_get_vertex_csr_device.restype = ctypes.c_int
+    L.hg_plan_get_vertex_csr_device.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]
+    L.hg_plan_get_schedule.restype = ctypes.c_int
+    L.hg_plan_get_schedule.argtypes = [vp, i32, vp, vp, vp]
+    L.hg_plan_workspace_bytes.restype = sz
+    L.hg_plan_workspace_bytes.argtypes = [vp, i32]
+    L.hg_aggr_fused_f32.restype = ctypes.c_int
+    L.hg_aggr_fused_f32.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, sz, i32, vp]
+    L.hg_gather_rows_f32.restype = ctypes.c_int
+    L.hg_gather_rows_f32.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+    L.hg_aggr_push_groups_f32.restype = ctypes.c_int
+    L.hg_aggr_push_groups_f32.argtypes = [i32, i32, i32, i64, vp, vp, vp, vp, vp, vp,
+                                          vp, vp, vp, vp, vp, vp]
+    _lib = L
+    return L
+
+
+def check(status):
+    if status != HG_OK:
+        msg = lib().hg_last_error()
+        raise HgError(status, (msg or b"").decode() or lib().hg_status_string(status).decode())

@@ -1,0 +1,391 @@
+// C ABI of libhgaggr.so (declared in include/hg_aggr.h): plan lifetime and the
+// launch functions.  Launch functions only enqueue on the caller's stream: no
+// allocation, no synchronisation, so they can be captured into a hipGraph.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "hg_kernels.h"
+
+namespace {
+
+int hip_fail(const char *what, hipError_t e) {
+  hg::set_error(std::string(what) + ": " + hipGetErrorString(e));
+  return HG_ERR_HIP;
+}
+
+#define HG_HIP(call)                                  \
+  do {                                                \
+    hipError_t e_ = (call);                           \
+    if (e_ != hipSuccess) return hip_fail(#call, e_); \
+  } while (0)
+
+size_t round256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int resolve_opts(const hg_plan_opts *in, hg::Opts &o) {
+  if (in) {
+    if (in->short_max > 0) o.short_max = in->short_max;
+    if (in->split_len > 0) o.split_len = in->split_len;
+    if (in->panel_rows > 0) o.panel_rows = in->panel_rows;
+    if (in->panel_nnz > 0) o.panel_nnz = in->panel_nnz;
+    o.flags = in->flags;
+  }
+  if (o.short_max > o.panel_nnz || o.split_len < o.short_max || o.panel_rows > 4096 ||
+      o.panel_nnz > 16384) {
+    hg::set_error("hg_plan_opts: need short_max <= panel_nnz <= 16384, split_len >= short_max, panel_rows <= 4096");
+    return HG_ERR_INVALID;
+  }
+  return HG_OK;
+}
+
+template <typename T>
+int upload(const std::vector<T> &h, T **d, int64_t &bytes) {
+  *d = nullptr;
+  if (h.empty()) return HG_OK;
+  const size_t n = h.size() * sizeof(T);
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(d), n);
+  if (e != hipSuccess) {
+    hg::set_error(std::string("hipMalloc(plan): ") + hipGetErrorString(e));
+    return e == hipErrorOutOfMemory ? HG_ERR_NOMEM : HG_ERR_HIP;
+  }
+  HG_HIP(hipMemcpy(*d, h.data(), n, hipMemcpyHostToDevice));
+  bytes += (int64_t)n;
+  return HG_OK;
+}
+
+int plan_upload(hg_plan *p) {
+  HG_HIP(hipGetDevice(&p->device));
+  int rc;
+  if ((rc = upload(p->ptr_v, &p->d_ptr_v, p->device_bytes)) != HG_OK) return rc;
+  if ((rc = upload(p->ind_v, &p->d_ind_v, p->device_bytes)) != HG_OK) return rc;
+  for (int h = 0; h < 2; h++) {
+    hg::Sched &s = p->sched[h];
+    if ((rc = upload(s.panels, &s.d_panels, p->device_bytes)) != HG_OK) return rc;
+    if ((rc = upload(s.tasks, &s.d_tasks, p->device_bytes)) != HG_OK) return rc;
+    if ((rc = upload(s.fixups, &s.d_fixups, p->device_bytes)) != HG_OK) return rc;
+  }
+  return HG_OK;
+}
+
+// workspace carve-up: [Xe: M*F][partials hop 0][partials hop 1]
+struct Carve {
+  size_t xe, part[2], total;
+};
+Carve carve(const hg_plan *p, int32_t F) {
+  Carve c;
+  c.xe = 0;
+  size_t off = round256((size_t)p->M * F * sizeof(float));
+  for (int h = 0; h < 2; h++) {
+    c.part[h] = off;
+    off += round256((size_t)p->sched[h].nslots * F * sizeof(float));
+  }
+  c.total = off;
+  return c;
+}
+
+int run_hop(const hg_plan *p, int hop, int32_t F, const int32_t *ptr, const int32_t *ind,
+            const float *src, const float *scaleA, const float *scaleB, float *dst,
+            float *partial, hipStream_t stream) {
+  const hg::Sched &s = p->sched[hop];
+  hg::GatherArgs a;
+  a.ptr = ptr;
+  a.ind = ind;
+  a.src = src;
+  a.dst = dst;
+  a.scaleA = scaleA;
+  a.scaleB = scaleB;
+  a.partial = partial;
+  a.panels = s.d_panels;
+  a.tasks = s.d_tasks;
+  a.npanels = (int32_t)s.panels.size();
+  a.ntasks = (int32_t)s.tasks.size();
+  a.n_task_blocks = (a.ntasks + 3) / 4;
+  a.F = F;
+  a.panel_rows = p->opts.panel_rows;
+  a.panel_nnz = p->opts.panel_nnz;
+  a.xcd_remap = (p->opts.flags & HG_PLAN_NO_XCD_REMAP) ? 0 : 1;
+  const bool vec4 = (F % 4 == 0) && aligned16(src) && aligned16(dst) && aligned16(partial);
+  hipError_t e = hg::launch_gather(a, (int)s.fixups.size(), s.d_fixups, vec4, stream);
+  if (e != hipSuccess) return hip_fail("gather_rows launch", e);
+  return HG_OK;
+}
+
+int check_call(const hg_plan *plan, int32_t F, const void *workspace, size_t workspace_bytes) {
+  if (!plan) {
+    hg::set_error("null plan");
+    return HG_ERR_INVALID;
+  }
+  if (plan->opts.flags & HG_PLAN_HOST_ONLY) {
+    hg::set_error("plan was built with HG_PLAN_HOST_ONLY and holds no device schedule");
+    return HG_ERR_INVALID;
+  }
+  if (F <= 0) {
+    hg::set_error("feature width must be positive");
+    return HG_ERR_INVALID;
+  }
+  if ((int64_t)std::max(plan->N, plan->M) * F >= ((int64_t)1 << 40)) {
+    hg::set_error("feature matrix too large");
+    return HG_ERR_INVALID;
+  }
+  const size_t need = carve(plan, F).total;
+  if (need > 0 && (!workspace || workspace_bytes < need)) {
+    hg::set_error("workspace too small: need " + std::to_string(need) + " bytes, got " +
+                  std::to_string(workspace_bytes));
+    return HG_ERR_WORKSPACE;
+  }
+  if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 255)) {
+    hg::set_error("workspace must be 256-byte aligned");
+    return HG_ERR_INVALID;
+  }
+  return HG_OK;
+}
+
+int plan_build(hg_plan **out, int32_t N, int32_t M, const int32_t *csrptr_t,
+               const int32_t *colind_t, const hg_plan_opts *opts) {
+  if (!out) {
+    hg::set_error("hg_plan_create: null output pointer");
+    return HG_ERR_INVALID;
+  }
+  *out = nullptr;
+  hg::Opts o;
+  int rc = resolve_opts(opts, o);
+  if (rc != HG_OK) return rc;
+  if ((rc = hg::validate_csr(M, N, csrptr_t, colind_t)) != HG_OK) return rc;
+  hg_plan *p = new (std::nothrow) hg_plan();
+  if (!p) {
+    hg::set_error("hg_plan_create: host allocation failed");
+    return HG_ERR_NOMEM;
+  }
+  try {
+    p->N = N;
+    p->M = M;
+    p->nnz = csrptr_t[M];
+    p->opts = o;
+    hg::transpose_csr(M, N, csrptr_t, colind_t, p->ptr_v, p->ind_v);
+    hg::build_sched(M, csrptr_t, o, p->sched[0]);
+    hg::build_sched(N, p->ptr_v.data(), o, p->sched[1]);
+  } catch (const std::bad_alloc &) {
+    delete p;
+    hg::set_error("hg_plan_create: host allocation failed");
+    return HG_ERR_NOMEM;
+  }
+  if (!(o.flags & HG_PLAN_HOST_ONLY)) {
+    rc = plan_upload(p);
+    if (rc != HG_OK) {
+      hg_plan_destroy(p);
+      return rc;
+    }
+  }
+  *out = p;
+  return HG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hg_plan_create_host(hg_plan **out, int32_t N, int32_t M, const int32_t *csrptr_t_host,
+                        const int32_t *colind_t_host, const hg_plan_opts *opts) {
+  return plan_build(out, N, M, csrptr_t_host, colind_t_host, opts);
+}
+
+int hg_plan_create_device(hg_plan **out, int32_t N, int32_t M, int64_t nnz,
+                          const int32_t *csrptr_t_dev, const int32_t *colind_t_dev,
+                          const hg_plan_opts *opts, hg_stream_t stream) {
+  if (!out || N < 0 || M < 0 || nnz < 0 || !csrptr_t_dev || (nnz > 0 && !colind_t_dev)) {
+    hg::set_error("hg_plan_create_device: bad argument");
+    return HG_ERR_INVALID;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  std::vector<int32_t> ptr, ind;
+  try {
+    ptr.resize((size_t)M + 1);
+    ind.resize((size_t)nnz);
+  } catch (const std::bad_alloc &) {
+    hg::set_error("hg_plan_create_device: host allocation failed");
+    return HG_ERR_NOMEM;
+  }
+  HG_HIP(hipMemcpyAsync(ptr.data(), csrptr_t_dev, ptr.size() * sizeof(int32_t),
+                        hipMemcpyDeviceToHost, s));
+  if (nnz > 0)
+    HG_HIP(hipMemcpyAsync(ind.data(), colind_t_dev, ind.size() * sizeof(int32_t),
+                          hipMemcpyDeviceToHost, s));
+  HG_HIP(hipStreamSynchronize(s));
+  if (ptr[M] != nnz) {
+    hg::set_error("hg_plan_create_device: csrptr_t[M] != nnz");
+    return HG_ERR_INVALID;
+  }
+  return plan_build(out, N, M, ptr.data(), ind.data(), opts);
+}
+
+void hg_plan_destroy(hg_plan *p) {
+  if (!p) return;
+  if (p->d_ptr_v) (void)hipFree(p->d_ptr_v);
+  if (p->d_ind_v) (void)hipFree(p->d_ind_v);
+  for (int h = 0; h < 2; h++) {
+    if (p->sched[h].d_panels) (void)hipFree(p->sched[h].d_panels);
+    if (p->sched[h].d_tasks) (void)hipFree(p->sched[h].d_tasks);
+    if (p->sched[h].d_fixups) (void)hipFree(p->sched[h].d_fixups);
+  }
+  delete p;
+}
+
+int hg_plan_get_info(const hg_plan *p, hg_plan_info *info) {
+  if (!p || !info) {
+    hg::set_error("hg_plan_get_info: null argument");
+    return HG_ERR_INVALID;
+  }
+  std::memset(info, 0, sizeof(*info));
+  info->N = p->N;
+  info->M = p->M;
+  info->nnz = p->nnz;
+  info->short_max = p->opts.short_max;
+  info->split_len = p->opts.split_len;
+  info->panel_rows = p->opts.panel_rows;
+  info->panel_nnz = p->opts.panel_nnz;
+  info->flags = p->opts.flags;
+  for (int h = 0; h < 2; h++) {
+    info->panels[h] = (int32_t)p->sched[h].panels.size();
+    info->tasks[h] = (int32_t)p->sched[h].tasks.size();
+    info->partials[h] = p->sched[h].nslots;
+    info->fixups[h] = (int32_t)p->sched[h].fixups.size();
+    info->max_len[h] = p->sched[h].max_len;
+  }
+  info->device_bytes = p->device_bytes;
+  return HG_OK;
+}
+
+int hg_plan_get_vertex_csr(const hg_plan *p, int32_t *ptr_v_host, int32_t *ind_v_host) {
+  if (!p || !ptr_v_host || (p->nnz > 0 && !ind_v_host)) {
+    hg::set_error("hg_plan_get_vertex_csr: null argument");
+    return HG_ERR_INVALID;
+  }
+  std::memcpy(ptr_v_host, p->ptr_v.data(), p->ptr_v.size() * sizeof(int32_t));
+  if (p->nnz > 0) std::memcpy(ind_v_host, p->ind_v.data(), p->ind_v.size() * sizeof(int32_t));
+  return HG_OK;
+}
+
+int hg_plan_get_vertex_csr_device(const hg_plan *p, const int32_t **ptr_v_dev,
+                                  const int32_t **ind_v_dev) {
+  if (!p || !ptr_v_dev || !ind_v_dev || (p->opts.flags & HG_PLAN_HOST_ONLY)) {
+    hg::set_error("hg_plan_get_vertex_csr_device: null argument or host-only plan");
+    return HG_ERR_INVALID;
+  }
+  *ptr_v_dev = p->d_ptr_v;
+  *ind_v_dev = p->d_ind_v;
+  return HG_OK;
+}
+
+int hg_plan_get_schedule(const hg_plan *p, int32_t hop, int32_t *panels, int32_t *tasks,
+                         int32_t *fixups) {
+  if (!p || (hop != 0 && hop != 1)) {
+    hg::set_error("hg_plan_get_schedule: bad argument");
+    return HG_ERR_INVALID;
+  }
+  const hg::Sched &s = p->sched[hop];
+  static_assert(sizeof(hg::Panel) == 16 && sizeof(hg::Task) == 16 && sizeof(hg::Fixup) == 16, "quad layout");
+  if (panels && !s.panels.empty()) std::memcpy(panels, s.panels.data(), s.panels.size() * sizeof(hg::Panel));
+  if (tasks && !s.tasks.empty()) std::memcpy(tasks, s.tasks.data(), s.tasks.size() * sizeof(hg::Task));
+  if (fixups && !s.fixups.empty()) std::memcpy(fixups, s.fixups.data(), s.fixups.size() * sizeof(hg::Fixup));
+  return HG_OK;
+}
+
+size_t hg_plan_workspace_bytes(const hg_plan *p, int32_t F) {
+  if (!p || F <= 0) return 0;
+  return carve(p, F).total;
+}
+
+int hg_gather_rows_f32(const hg_plan *plan, int32_t hop, int32_t F, const int32_t *csrptr_t,
+                       const int32_t *colind_t, const float *src, const float *scaleA,
+                       const float *scaleB, float *dst, void *workspace, size_t workspace_bytes,
+                       hg_stream_t stream) {
+  int rc = check_call(plan, F, workspace, workspace_bytes);
+  if (rc != HG_OK) return rc;
+  if ((hop != 0 && hop != 1) || !src || !dst || (hop == 0 && (!csrptr_t || (plan->nnz > 0 && !colind_t)))) {
+    hg::set_error("hg_gather_rows_f32: bad argument");
+    return HG_ERR_INVALID;
+  }
+  const Carve c = carve(plan, F);
+  float *partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + c.part[hop]);
+  const int32_t *ptr = hop == 0 ? csrptr_t : plan->d_ptr_v;
+  const int32_t *ind = hop == 0 ? colind_t : plan->d_ind_v;
+  return run_hop(plan, hop, F, ptr, ind, src, scaleA, scaleB, dst, partial,
+                 static_cast<hipStream_t>(stream));
+}
+
+int hg_aggr_push_groups_f32(int32_t N, int32_t M, int32_t F, int64_t n_group,
+                            const int32_t *group_key, const int32_t *group_row,
+                            const int32_t *group_st, const int32_t *group_ed,
+                            const int32_t *csrptr_t, const int32_t *colind_t, const float *X,
+                            const float *degE, const float *degV, const float *W, float *Y,
+                            hg_stream_t stream) {
+  if (N < 0 || M < 0 || F <= 0 || n_group < 0 || !X || !Y || !colind_t) {
+    hg::set_error("hg_aggr_push_groups_f32: bad argument");
+    return HG_ERR_INVALID;
+  }
+  if (group_key ? (!group_row || !group_st || !group_ed) : (!csrptr_t || n_group != M)) {
+    hg::set_error("hg_aggr_push_groups_f32: need all four group arrays, or csrptr_t with n_group == M");
+    return HG_ERR_INVALID;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  HG_HIP(hipMemsetAsync(Y, 0, (size_t)N * F * sizeof(float), s));
+  hg::PushArgs a;
+  a.n_group = n_group;
+  a.group_key = group_key;
+  a.group_row = group_row;
+  a.group_st = group_st;
+  a.group_ed = group_ed;
+  a.csrptr_t = csrptr_t;
+  a.colind_t = colind_t;
+  a.X = X;
+  a.degE = degE;
+  a.degV = degV;
+  a.W = W;
+  a.Y = Y;
+  a.F = F;
+  hipError_t e = hg::launch_push(a, s);
+  if (e != hipSuccess) return hip_fail("push_groups launch", e);
+  return HG_OK;
+}
+
+int hg_aggr_fused_f32(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
+                      const int32_t *colind_t, const float *X, const float *degE,
+                      const float *degV, const float *W, float *Y, void *workspace,
+                      size_t workspace_bytes, int32_t variant, hg_stream_t stream) {
+  if (variant == HG_VARIANT_PUSH_ATOMIC) {
+    if (!plan) {
+      hg::set_error("null plan");
+      return HG_ERR_INVALID;
+    }
+    return hg_aggr_push_groups_f32(plan->N, plan->M, F, plan->M, nullptr, nullptr, nullptr, nullptr,
+                                   csrptr_t, colind_t, X, degE, degV, W, Y, stream);
+  }
+  if (variant != HG_VARIANT_AUTO && variant != HG_VARIANT_PULL) {
+    hg::set_error("hg_aggr_fused_f32: unknown variant");
+    return HG_ERR_UNSUPPORTED;
+  }
+  int rc = check_call(plan, F, workspace, workspace_bytes);
+  if (rc != HG_OK) return rc;
+  if (!csrptr_t || (plan->nnz > 0 && !colind_t) || !X || !Y) {
+    hg::set_error("hg_aggr_fused_f32: null array");
+    return HG_ERR_INVALID;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const Carve c = carve(plan, F);
+  char *ws = static_cast<char *>(workspace);
+  float *Xe = reinterpret_cast<float *>(ws + c.xe);
+  // hop 1: Xe[e] = ((sum_{u in e} X[u]) * degE[e]) * W[e]
+  rc = run_hop(plan, 0, F, csrptr_t, colind_t, X, degE, W, Xe,
+               reinterpret_cast<float *>(ws + c.part[0]), s);
+  if (rc != HG_OK) return rc;
+  // hop 2: Y[v] = (sum_{e contains v} Xe[e]) * degV[v]
+  return run_hop(plan, 1, F, plan->d_ptr_v, plan->d_ind_v, Xe, degV, nullptr, Y,
+                 reinterpret_cast<float *>(ws + c.part[1]), s);
+}
+
+}  // extern "C"

@@ -1,0 +1,296 @@
+// gfx950 (MI355X, CDNA4) kernels of libhgaggr: the two hops of the fused
+// vertex -> hyperedge -> vertex aggregation as atomic-free row gathers, plus the
+// reference-style register-fused push kernel with fp32 atomics.
+//
+// Layout: a feature row of F floats is spread over LPR consecutive lanes (VEC
+// floats each), so a 64-lane wavefront holds G = 64/LPR rows at once and every
+// row access is one contiguous LPR*VEC*4-byte segment (F = 32: 8 lanes x
+// dwordx4 = one 128-byte line per row, 8 rows per wave instruction).
+#include <hip/hip_runtime.h>
+
+#include "hg_kernels.h"
+
+namespace hg {
+
+template <int VEC> struct Vec;
+template <> struct Vec<1> {
+  float x;
+  __device__ __forceinline__ static Vec zero() { return Vec{0.f}; }
+  __device__ __forceinline__ static Vec load(const float *p) { return Vec{*p}; }
+  __device__ __forceinline__ void store(float *p) const { *p = x; }
+  __device__ __forceinline__ void add(const Vec &o) { x += o.x; }
+  __device__ __forceinline__ void mul(float s) { x *= s; }
+  __device__ __forceinline__ void xor_reduce(int off) { x += __shfl_xor(x, off, 64); }
+};
+template <> struct Vec<4> {
+  float4 v;
+  __device__ __forceinline__ static Vec zero() { return Vec{make_float4(0.f, 0.f, 0.f, 0.f)}; }
+  __device__ __forceinline__ static Vec load(const float *p) {
+    return Vec{*reinterpret_cast<const float4 *>(p)};
+  }
+  __device__ __forceinline__ void store(float *p) const { *reinterpret_cast<float4 *>(p) = v; }
+  __device__ __forceinline__ void add(const Vec &o) {
+    v.x += o.v.x; v.y += o.v.y; v.z += o.v.z; v.w += o.v.w;
+  }
+  __device__ __forceinline__ void mul(float s) { v.x *= s; v.y *= s; v.z *= s; v.w *= s; }
+  __device__ __forceinline__ void xor_reduce(int off) {
+    v.x += __shfl_xor(v.x, off, 64); v.y += __shfl_xor(v.y, off, 64);
+    v.z += __shfl_xor(v.z, off, 64); v.w += __shfl_xor(v.w, off, 64);
+  }
+};
+
+// dst[r,:] = scaleB[r] * (scaleA[r] * sum_{p in row r} src[ind[p],:])
+//
+// Workgroups [0, n_task_blocks) run wave tasks (one long-row slice per wave, its
+// entries strided over the wave's G row groups, then a cross-group shuffle
+// reduction).  The remaining workgroups each own one row panel: the panel's
+// row pointers, row scales and index slice are staged into LDS with coalesced
+// loads, then every LPR-lane group walks a contiguous run of the panel's rows as
+// one flat entry stream, U row loads in flight, adding in CSR order (so short
+// rows reproduce the CPU reference's summation order exactly).
+template <int LPR, int VEC, int U>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const GatherArgs a) {
+  constexpr int G = 64 / LPR;    // row groups per wave
+  constexpr int NG = 256 / LPR;  // row groups per workgroup
+  using V = Vec<VEC>;
+  extern __shared__ int32_t smem[];
+
+  const int tid = threadIdx.x;
+  const int gl = tid & (LPR - 1);
+  const int col = (blockIdx.y * LPR + gl) * VEC;
+  const bool col_ok = col < a.F;
+  const int64_t F = a.F;
+  int b = blockIdx.x;
+
+  if (b < a.n_task_blocks) {
+    const int t = __builtin_amdgcn_readfirstlane(b * 4 + (tid >> 6));
+    if (t >= a.ntasks) return;
+    const Task tk = a.tasks[t];
+    const int g = (tid & 63) / LPR;
+    V acc = V::zero();
+    for (int p = tk.beg + g; p < tk.end; p += G * U) {
+      V v[U];
+#pragma unroll
+      for (int k = 0; k < U; k++) {
+        const int q = p + k * G;
+        const bool ok = col_ok && q < tk.end;
+        const int64_t idx = ok ? a.ind[q] : 0;
+        v[k] = ok ? V::load(a.src + idx * F + col) : V::zero();
+      }
+#pragma unroll
+      for (int k = 0; k < U; k++) acc.add(v[k]);
+    }
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) acc.xor_reduce(off);
+    if (g == 0 && col_ok) {
+      if (tk.slot < 0) {
+        if (a.scaleA) acc.mul(a.scaleA[tk.row]);
+        if (a.scaleB) acc.mul(a.scaleB[tk.row]);
+        acc.store(a.dst + (int64_t)tk.row * F + col);
+      } else {
+        acc.store(a.partial + (int64_t)tk.slot * F + col);
+      }
+    }
+    return;
+  }
+
+  b -= a.n_task_blocks;
+  if (a.xcd_remap) {
+    // workgroups are dealt round-robin to the 8 XCDs; give each XCD one
+    // contiguous run of panels so neighbouring panels share an L2
+    const int x = b & 7, i = b >> 3;
+    const int cpx = a.npanels >> 3, rem = a.npanels & 7;
+    b = x * cpx + (x < rem ? x : rem) + i;
+  }
+  const Panel pn = a.panels[b];
+  int32_t *sptr = smem;                                         // [panel_rows + 1]
+  float *sA = reinterpret_cast<float *>(smem + a.panel_rows + 1);  // [panel_rows]
+  float *sB = sA + a.panel_rows;                                // [panel_rows]
+  int32_t *sind = reinterpret_cast<int32_t *>(sB + a.panel_rows);  // [panel_nnz]
+
+  for (int i = tid; i <= pn.nrows; i += 256) sptr[i] = a.ptr[pn.row0 + i] - pn.nnz0;
+  if (a.scaleA)
+    for (int i = tid; i < pn.nrows; i += 256) sA[i] = a.scaleA[pn.row0 + i];
+  if (a.scaleB)
+    for (int i = tid; i < pn.nrows; i += 256) sB[i] = a.scaleB[pn.row0 + i];
+  for (int i = tid; i < pn.nnz_cnt; i += 256) sind[i] = a.ind[pn.nnz0 + i];
+  __syncthreads();
+
+  const int g = tid / LPR;
+  const int rpg = (pn.nrows + NG - 1) / NG;
+  int r = min(g * rpg, pn.nrows);
+  const int re = min(r + rpg, pn.nrows);
+  if (r >= re) return;
+
+  auto flush = [&](int row, V acc) {
+    if (sptr[row + 1] > sptr[row]) {  // an empty row stays exactly 0 (degE may be inf)
+      if (a.scaleA) acc.mul(sA[row]);
+      if (a.scaleB) acc.mul(sB[row]);
+    }
+    if (col_ok) acc.store(a.dst + (int64_t)(pn.row0 + row) * F + col);
+  };
+
+  int pos = sptr[r];
+  const int stop = sptr[re];
+  int row_end = sptr[r + 1];
+  V acc = V::zero();
+  while (pos < stop) {
+    const int n = min(U, stop - pos);
+    V v[U];
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+      const int64_t idx = sind[pos + min(k, n - 1)];
+      v[k] = col_ok ? V::load(a.src + idx * F + col) : V::zero();
+    }
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+      if (k < n) {
+        while (row_end <= pos + k) {
+          flush(r, acc);
+          acc = V::zero();
+          r++;
+          row_end = sptr[r + 1];
+        }
+        acc.add(v[k]);
+      }
+    }
+    pos += n;
+  }
+  while (r < re) {
+    flush(r, acc);
+    acc = V::zero();
+    r++;
+  }
+}
+
+// out[row,:] = scaleB * (scaleA * sum_k partial[first+k,:]), slots in order.
+template <int LPR, int VEC>
+__global__ __launch_bounds__(256) void fixup_rows_kernel(const GatherArgs a, const Fixup *fixups,
+                                                         int nfix) {
+  using V = Vec<VEC>;
+  const int tid = threadIdx.x;
+  const int gl = tid & (LPR - 1);
+  const int col = (blockIdx.y * LPR + gl) * VEC;
+  const int f = blockIdx.x * (256 / LPR) + tid / LPR;
+  if (f >= nfix || col >= a.F) return;
+  const Fixup fx = fixups[f];
+  const int64_t F = a.F;
+  V acc = V::zero();
+  for (int k = 0; k < fx.count; k++) acc.add(V::load(a.partial + (int64_t)(fx.first + k) * F + col));
+  if (a.scaleA) acc.mul(a.scaleA[fx.row]);
+  if (a.scaleB) acc.mul(a.scaleB[fx.row]);
+  acc.store(a.dst + (int64_t)fx.row * F + col);
+}
+
+// The reference's register-fused scheme on wave64: LPR lanes = LPR feature
+// columns of one task, 64/LPR tasks per wave.  Gather-sum the read partition,
+// scale by degE*W, scatter acc*degV[v] to the write partition with hardware
+// fp32 atomics (global_atomic_add_f32, one contiguous LPR*4-byte segment per
+// destination row).
+template <int LPR>
+__global__ __launch_bounds__(256) void push_groups_kernel(const PushArgs a) {
+  const int tid = threadIdx.x;
+  const int64_t gid = (int64_t)blockIdx.x * (256 / LPR) + tid / LPR;
+  const int k = blockIdx.y * LPR + (tid & (LPR - 1));
+  if (gid >= a.n_group || k >= a.F) return;
+  const int64_t F = a.F;
+  int eid, rd_start, rd_end, wr_start, wr_end;
+  if (a.group_key) {
+    eid = a.group_row[gid];
+    const int rid = a.group_st[gid], wid = a.group_ed[gid];
+    rd_start = a.group_key[rid];
+    rd_end = a.group_key[rid + 1];
+    wr_start = a.group_key[wid];
+    wr_end = a.group_key[wid + 1];
+  } else {
+    eid = (int)gid;
+    rd_start = wr_start = a.csrptr_t[eid];
+    rd_end = wr_end = a.csrptr_t[eid + 1];
+  }
+  float acc = 0.f;
+  for (int p = rd_start; p < rd_end; p++) acc += a.X[(int64_t)a.colind_t[p] * F + k];
+  const float degE_val = a.degE ? a.degE[eid] : 1.f;
+  const float W_val = a.W ? a.W[eid] : 1.f;
+  acc *= degE_val * W_val;
+  for (int p = wr_start; p < wr_end; p++) {
+    const int64_t v = a.colind_t[p];
+    const float degV_val = a.degV ? a.degV[v] : 1.f;
+    atomicAdd(a.Y + v * F + k, acc * degV_val);
+  }
+}
+
+static inline int next_pow2(int x) {
+  int p = 1;
+  while (p < x) p <<= 1;
+  return p;
+}
+
+template <int LPR, int VEC>
+static hipError_t launch_gather_t(const GatherArgs &a, int nfix, const Fixup *fixups,
+                                  hipStream_t stream) {
+  constexpr int U = 4;
+  const int col_tiles = (a.F + LPR * VEC - 1) / (LPR * VEC);
+  const int nblocks = a.n_task_blocks + a.npanels;
+  if (nblocks > 0) {
+    const size_t lds = (size_t)(3 * a.panel_rows + 1 + a.panel_nnz) * sizeof(int32_t);
+    hipLaunchKernelGGL((gather_rows_kernel<LPR, VEC, U>), dim3(nblocks, col_tiles), dim3(256), lds,
+                       stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  if (nfix > 0) {
+    const int per_block = 256 / LPR;
+    hipLaunchKernelGGL((fixup_rows_kernel<LPR, VEC>), dim3((nfix + per_block - 1) / per_block, col_tiles),
+                       dim3(256), 0, stream, a, fixups, nfix);
+    return hipGetLastError();
+  }
+  return hipSuccess;
+}
+
+hipError_t launch_gather(const GatherArgs &a, int nfix, const Fixup *fixups, bool vec4,
+                         hipStream_t stream) {
+  const int lanes = vec4 ? a.F / 4 : a.F;
+  const int lpr = std::min(64, next_pow2(std::max(lanes, 1)));
+#define HG_CASE(L)                                                        \
+  case L:                                                                 \
+    return vec4 ? launch_gather_t<L, 4>(a, nfix, fixups, stream)          \
+                : launch_gather_t<L, 1>(a, nfix, fixups, stream);
+  switch (lpr) {
+    HG_CASE(1)
+    HG_CASE(2)
+    HG_CASE(4)
+    HG_CASE(8)
+    HG_CASE(16)
+    HG_CASE(32)
+    HG_CASE(64)
+  }
+#undef HG_CASE
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_push(const PushArgs &a, hipStream_t stream) {
+  const int lpr = std::min(64, next_pow2(std::max(a.F, 1)));
+  const int per_block = 256 / lpr;
+  const int col_tiles = (a.F + lpr - 1) / lpr;
+  const int64_t nblocks = (a.n_group + per_block - 1) / per_block;
+  if (nblocks == 0) return hipSuccess;
+  if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
+#define HG_CASE(L)                                                                               \
+  case L:                                                                                        \
+    hipLaunchKernelGGL((push_groups_kernel<L>), dim3((unsigned)nblocks, col_tiles), dim3(256), 0, \
+                       stream, a);                                                               \
+    break;
+  switch (lpr) {
+    HG_CASE(1)
+    HG_CASE(2)
+    HG_CASE(4)
+    HG_CASE(8)
+    HG_CASE(16)
+    HG_CASE(32)
+    HG_CASE(64)
+  }
+#undef HG_CASE
+  return hipGetLastError();
+}
+
+}  // namespace hg

@@ -1,0 +1,86 @@
+"""Multi-GPU: one process per GPU, hypergraph sharded by hyperedge group.
+
+The reference is single-GPU; this is new work defined by
+BASELINE.json.  Each hyperedge's two hops need only X, so hyperedges are cut
+into `world` contiguous groups balanced by incidence count; every rank holds X
+and degV replicated, aggregates its own hyperedges into a dense partial
+Y_r [N, F], and one sum all-reduce over RCCL (backend "nccl" on ROCm) yields Y
+on every rank:  Y = sum_r degV . H_r (degE_r . W_r . (H_r^T X)).
+
+When no vertex is shared between shards (a batch of independent hypergraphs
+sharded by graph) the partials have disjoint row support; `exchange="none"`
+then skips the collective and leaves Y row-sharded (each rank owns the rows of
+its graphs), which is the weak-scaling form bench.py reports.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .synth import Incidence
+
+
+def partition_hyperedges(csrptr, world):
+    """Contiguous hyperedge ranges [lo_r, hi_r) with near-equal incidence counts."""
+    csrptr = np.asarray(csrptr, np.int64)
+    M = csrptr.shape[0] - 1
+    nnz = int(csrptr[-1])
+    cuts = [0]
+    for r in range(1, world):
+        cuts.append(int(np.searchsorted(csrptr, nnz * r / world, side="left")))
+    cuts.append(M)
+    cuts = np.maximum.accumulate(np.minimum(cuts, M))
+    return [(int(cuts[r]), int(cuts[r + 1])) for r in range(world)]
+
+
+def local_incidence(inc, lo, hi):
+    """Rows [lo, hi) of H_T, vertex ids unchanged (X stays replicated)."""
+    ptr = inc.csrptr[lo:hi + 1].astype(np.int64)
+    return Incidence(inc.N, hi - lo, ptr - ptr[0], inc.colind[ptr[0]:ptr[-1]],
+                     name="%s[%d:%d]" % (inc.name, lo, hi))
+
+
+def shared_vertices(inc, parts):
+    """Vertices touched by more than one shard (the rows a sparse exchange would move)."""
+    owner_count = np.zeros(inc.N, np.int32)
+    for lo, hi in parts:
+        v = np.unique(inc.colind[inc.csrptr[lo]:inc.csrptr[hi]])
+        owner_count[v] += 1
+    return np.nonzero(owner_count > 1)[0]
+
+
+class ShardedAggregator:
+    """Per-rank object.  `local_op(inc_local, X, degE_local, degV, W_local) -> Y_partial`
+    defaults to the HIP path; tests inject a CPU checker to exercise the sharding
+    and the collective over gloo without a GPU."""
+
+    def __init__(self, inc, rank=None, world=None, device=None, local_op=None, exchange="allreduce"):
+        self.rank = dist.get_rank() if rank is None else rank
+        self.world = dist.get_world_size() if world is None else world
+        self.parts = partition_hyperedges(inc.csrptr, self.world)
+        self.lo, self.hi = self.parts[self.rank]
+        self.local = local_incidence(inc, self.lo, self.hi)
+        self.N, self.M = inc.N, inc.M
+        self.device = device
+        self.exchange = exchange
+        self._local_op = local_op or self._hip_local_op
+        self._hip = None
+
+    def _hip_local_op(self, inc_local, X, degE, degV, W):
+        from .plan import Plan
+        if self._hip is None:
+            ptr = torch.from_numpy(inc_local.csrptr).to(X.device)
+            ind = torch.from_numpy(inc_local.colind).to(X.device)
+            self._hip = (Plan.from_tensors(self.N, ptr, ind), ptr, ind)
+        plan, ptr, ind = self._hip
+        return plan.aggregate(ptr, ind, X, degE, degV, W)
+
+    def slice_edge_vector(self, t):
+        """degE / W are per hyperedge: each rank uses its own slice."""
+        return None if t is None else t.reshape(-1)[self.lo:self.hi].contiguous()
+
+    def aggregate(self, X, degE=None, degV=None, W=None):
+        Y = self._local_op(self.local, X, self.slice_edge_vector(degE),
+                           None if degV is None else degV.reshape(-1), self.slice_edge_vector(W))
+        if self.exchange == "allreduce" and self.world > 1:
+            dist.all_reduce(Y, op=dist.ReduceOp.SUM)
+        return Y

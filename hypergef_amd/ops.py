@@ -1,0 +1,158 @@
+"""Operator surface of the reference, on the MI355X backend.
+
+Mirrors, name for name and argument for argument:
+  * the pybind modules `hgnnaggr` (HyperGsys/source/hgnnaggr/hgnnaggr.cc:122-151)
+    and `unignnaggr` (HyperGsys/source/unignnaggr/unignnaggr.cc:81-102) --
+    exposed as `hypergef_amd.hgnnaggr` / `hypergef_amd.unignnaggr` and, after
+    `hypergef_amd.install_dropin()`, as top-level `hgnnaggr` / `unignnaggr`;
+  * the Python wrappers `HGNNAggr`, `UniGNNConvdeg`, `UniGNNConv`
+    (HyperGsys/source/python/hgnnaggr.py:6-7, unignnconv.py:6-10).
+
+The four schedule tensors (`balan_key, balan_row, group_st, group_ed`) stay in
+the signatures.  The default kernels derive their own wave64 schedule from
+`csrptr_t` / `indices_t` (cached per hypergraph); with
+`set_variant("push_groups")` the reference's own scheme runs on exactly the
+tasks those tensors describe.
+
+Backward: the reference returns `forward(grad_out)` for every sum operator
+(hgnnaggr.cc:51-64, unignnaggr.cc:36-49, 65-78).  That equals the true adjoint
+only when degV is absent; `set_backward("adjoint")` selects
+H diag(degE W) H^T diag(degV) grad instead.  Default: "reference".
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from .plan import Plan, cached_plan, _check_feat, _check_index, _ptr, _stream_handle
+
+_STATE = {"variant": "auto", "backward": "reference"}
+
+
+def set_variant(name):
+    """'auto' | 'pull' | 'push_atomic' (plan-free hyperedge tasks) | 'push_groups'
+    (the caller's group_* tensors drive the reference-style kernel)."""
+    if name not in ("auto", "pull", "push_atomic", "push_groups"):
+        raise ValueError("unknown variant %r" % (name,))
+    _STATE["variant"] = name
+
+
+def set_backward(mode):
+    if mode not in ("reference", "adjoint"):
+        raise ValueError("backward mode must be 'reference' or 'adjoint'")
+    _STATE["backward"] = mode
+
+
+def _flat(t):
+    # degE / degV / W are read as flat arrays: [M] and [M,1] both valid
+    return None if t is None else t.reshape(-1)
+
+
+def _forward(sched, csrptr_t, indices_t, node_feat, degE, degV, W):
+    _check_feat(node_feat, "node_feat")
+    _check_index(csrptr_t, "csrptr_t")
+    _check_index(indices_t, "indices_t")
+    if node_feat.dim() != 2:
+        raise ValueError("node_feat must be [N, F]")
+    N, F = node_feat.shape
+    degE, degV, W = _flat(degE), _flat(degV), _flat(W)
+    variant = _STATE["variant"]
+    if variant == "push_groups":
+        key, row, st, ed = sched
+        for n, t in (("balan_key", key), ("balan_row", row), ("group_st", st), ("group_ed", ed)):
+            _check_index(t, n)
+        M = csrptr_t.numel() - 1
+        for name, t, n in (("degE", degE, M), ("degV", degV, N), ("W", W, M)):
+            if t is not None:
+                _check_feat(t, name, device=node_feat.device)
+                if t.numel() != n:
+                    raise ValueError("%s must have %d elements" % (name, n))
+        Y = torch.empty((N, F), dtype=torch.float32, device=node_feat.device)
+        with torch.cuda.device(node_feat.device):
+            _lib.check(_lib.lib().hg_aggr_push_groups_f32(
+                N, M, F, row.numel(), _ptr(key), _ptr(row), _ptr(st), _ptr(ed),
+                _ptr(csrptr_t), _ptr(indices_t), _ptr(node_feat), _ptr(degE), _ptr(degV), _ptr(W),
+                _ptr(Y), _stream_handle(node_feat.device)))
+        return Y
+    plan = cached_plan(N, csrptr_t, indices_t)
+    return plan.aggregate(csrptr_t, indices_t, node_feat, degE, degV, W, variant=variant)
+
+
+class _SumAggr(torch.autograd.Function):
+    """One autograd node for all three sum operators (degE/degV/W optional)."""
+
+    @staticmethod
+    def forward(ctx, balan_key, balan_row, group_st, group_ed, csrptr_t, indices_t, node_feat,
+                degE, degV, W):
+        out = _forward((balan_key, balan_row, group_st, group_ed), csrptr_t, indices_t, node_feat,
+                       degE, degV, W)
+        ctx.sched = (balan_key, balan_row, group_st, group_ed)
+        ctx.graph = (csrptr_t, indices_t)
+        ctx.scales = (degE, degV, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        grad_out = grad_out.contiguous()
+        degE, degV, W = ctx.scales
+        csrptr_t, indices_t = ctx.graph
+        if _STATE["backward"] == "reference" or degV is None:
+            g = _forward(ctx.sched, csrptr_t, indices_t, grad_out, degE, degV, W)
+        else:
+            g = _forward(ctx.sched, csrptr_t, indices_t, grad_out * degV.reshape(-1, 1), degE, None, W)
+        return (None,) * 6 + (g, None, None, None)
+
+
+# ---- module `hgnnaggr` (hgnnaggr.cc:122-151) ---------------------------------
+
+def hgnnaggr(balan_key, balan_row, group_st, group_ed, csrptr_t, indices_t, node_feat, degE, degV, W):
+    """hgnnaggr with fused degE and degV."""
+    return _SumAggr.apply(balan_key, balan_row, group_st, group_ed, csrptr_t, indices_t, node_feat,
+                          degE, degV, W)
+
+
+def hgnnaggr_mean(csrptr_t, indices_t, node_feat, degE, degV, W):
+    """hgnnaggr with f1 mean (hgnnaggr.cc:131-136)."""
+    raise NotImplementedError("first_aggr='mean' is not built yet (SURVEY.md 8(f) item 4)")
+
+
+def hgnnaggr_max(csrptr_t, indices_t, node_feat, degE, degV, W):
+    """hgnnaggr with f1 max (hgnnaggr.cc:138-144)."""
+    raise NotImplementedError("first_aggr='max' is not built yet (SURVEY.md 8(f) item 4)")
+
+
+# ---- module `unignnaggr` (unignnaggr.cc:81-102) ------------------------------
+
+def unignnaggrdeg(balan_key, balan_row, group_st, group_ed, csrptr_t, indices_t, node_feat, degE, degV):
+    return _SumAggr.apply(balan_key, balan_row, group_st, group_ed, csrptr_t, indices_t, node_feat,
+                          degE, degV, None)
+
+
+def unignnaggr(balan_key, balan_row, group_st, group_ed, csrptr_t, indices_t, node_feat):
+    return _SumAggr.apply(balan_key, balan_row, group_st, group_ed, csrptr_t, indices_t, node_feat,
+                          None, None, None)
+
+
+# the names the reference's Python wrapper actually calls (unignnconv.py:7,10);
+# the reference module does not export them (defect D4), this one does
+unignnconvdeg = unignnaggrdeg
+unignnconv = unignnaggr
+
+
+# ---- wrappers (source/python/hgnnaggr.py, unignnconv.py) ----------------------
+
+def HGNNAggr(hyperg, in_feat, degE, degV, Wdiag, first_aggr="sum"):
+    """first_aggr is accepted and ignored, as in the reference (hgnnaggr.py:6-7);
+    it has a default so the reference test's 5-argument call works (hgnn_test.py:89)."""
+    return hgnnaggr(hyperg.group_key, hyperg.group_row, hyperg.group_start, hyperg.group_end,
+                    hyperg.H_T_csrptr, hyperg.H_T_colind, in_feat, degE, degV, Wdiag)
+
+
+def UniGNNConvdeg(dl, in_feat, degE, degV):
+    return unignnaggrdeg(dl.group_key, dl.group_row, dl.group_start, dl.group_end,
+                         dl.H_T_csrptr, dl.H_T_colind, in_feat, degE, degV)
+
+
+def UniGNNConv(dl, in_feat):
+    return unignnaggr(dl.group_key, dl.group_row, dl.group_start, dl.group_end,
+                      dl.H_T_csrptr, dl.H_T_colind, in_feat)

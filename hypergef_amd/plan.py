@@ -1,0 +1,213 @@
+"""Plan objects: this backend's schedule for one hypergraph (include/hg_aggr.h).
+
+The plan plays the role the reference's `group_key/group_row/group_start/
+group_end` tensors play for its kernels (HyperGsys/hypergraph.py:96-101): it is
+built once per hypergraph from `H_T_csrptr` / `H_T_colind` and reused by every
+aggregation call.  The reference operators receive those two tensors on every
+call, so a small cache keyed on them keeps the call signature unchanged.
+"""
+import collections
+import ctypes
+import threading
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream_handle(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def make_opts(short_max=0, split_len=0, panel_rows=0, panel_nnz=0, xcd_remap=True, host_only=False):
+    flags = 0
+    if host_only:
+        flags |= _lib.HG_PLAN_HOST_ONLY
+    if not xcd_remap:
+        flags |= _lib.HG_PLAN_NO_XCD_REMAP
+    return _lib.PlanOpts(short_max, split_len, panel_rows, panel_nnz, flags)
+
+
+class Plan:
+    """Owns an `hg_plan*`."""
+
+    def __init__(self, handle, device=None):
+        self._h = handle
+        self.device = device
+        info = _lib.PlanInfo()
+        _lib.check(_lib.lib().hg_plan_get_info(self._h, ctypes.byref(info)))
+        self.info = info.as_dict()
+        self.N, self.M, self.nnz = info.N, info.M, info.nnz
+
+    @classmethod
+    def from_host(cls, N, M, csrptr_t, colind_t, opts=None, device=None):
+        """csrptr_t / colind_t: host int32 arrays of H_T.  With a host-only
+        `opts` nothing touches the GPU (used by the CPU tests)."""
+        csrptr_t = np.ascontiguousarray(csrptr_t, dtype=np.int32)
+        colind_t = np.ascontiguousarray(colind_t, dtype=np.int32)
+        if csrptr_t.shape[0] != M + 1:
+            raise ValueError("csrptr_t must have M + 1 entries")
+        if int(csrptr_t[-1]) != colind_t.shape[0]:
+            raise ValueError("csrptr_t[M] must equal len(colind_t)")
+        h = ctypes.c_void_p()
+        ctx = torch.cuda.device(device) if device is not None else _NullCtx()
+        with ctx:
+            _lib.check(_lib.lib().hg_plan_create_host(
+                ctypes.byref(h), N, M, csrptr_t.ctypes.data_as(ctypes.c_void_p),
+                colind_t.ctypes.data_as(ctypes.c_void_p),
+                ctypes.byref(opts) if opts is not None else None))
+        return cls(h, device)
+
+    @classmethod
+    def from_tensors(cls, N, csrptr_t, colind_t, opts=None):
+        """csrptr_t / colind_t: int32 device tensors (the reference's
+        `hyperg.H_T_csrptr` / `hyperg.H_T_colind`)."""
+        _check_index(csrptr_t, "csrptr_t")
+        _check_index(colind_t, "indices_t")
+        M = csrptr_t.numel() - 1
+        h = ctypes.c_void_p()
+        with torch.cuda.device(csrptr_t.device):
+            _lib.check(_lib.lib().hg_plan_create_device(
+                ctypes.byref(h), N, M, colind_t.numel(), _ptr(csrptr_t), _ptr(colind_t),
+                ctypes.byref(opts) if opts is not None else None, _stream_handle(csrptr_t.device)))
+        return cls(h, csrptr_t.device)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.lib().hg_plan_destroy(h)
+            except Exception:
+                pass
+
+    def vertex_csr(self):
+        """Host copy of the derived H CSR: (ptr_v [N+1], ind_v [nnz])."""
+        ptr_v = np.empty(self.N + 1, np.int32)
+        ind_v = np.empty(self.nnz, np.int32)
+        _lib.check(_lib.lib().hg_plan_get_vertex_csr(
+            self._h, ptr_v.ctypes.data_as(ctypes.c_void_p), ind_v.ctypes.data_as(ctypes.c_void_p)))
+        return ptr_v, ind_v
+
+    def schedule(self, hop):
+        """Host copy of hop's schedule: dict of int32 [n,4] arrays (see hg_aggr.h)."""
+        out = {k: np.zeros((self.info[k][hop], 4), np.int32) for k in ("panels", "tasks", "fixups")}
+        _lib.check(_lib.lib().hg_plan_get_schedule(
+            self._h, hop, *(out[k].ctypes.data_as(ctypes.c_void_p) for k in ("panels", "tasks", "fixups"))))
+        return out
+
+    def workspace_bytes(self, F):
+        return int(_lib.lib().hg_plan_workspace_bytes(self._h, F))
+
+    def _workspace(self, F, device):
+        nbytes = self.workspace_bytes(F)
+        # torch's caching allocator returns 512-byte aligned blocks and is stream-ordered
+        return torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device), nbytes
+
+    def aggregate(self, csrptr_t, colind_t, X, degE=None, degV=None, W=None, variant="auto",
+                  out=None, workspace=None):
+        """Y = degV . H (degE . W . (H^T X)) on X's device, current stream."""
+        _check_feat(X, "node_feat")
+        if X.shape[0] != self.N:
+            raise ValueError("node_feat has %d rows, hypergraph has %d vertices" % (X.shape[0], self.N))
+        F = X.shape[1]
+        for name, t, n in (("degE", degE, self.M), ("degV", degV, self.N), ("W", W, self.M)):
+            if t is not None:
+                _check_feat(t, name, device=X.device)
+                if t.numel() != n:
+                    raise ValueError("%s must have %d elements, got %d" % (name, n, t.numel()))
+        Y = out if out is not None else torch.empty((self.N, F), dtype=torch.float32, device=X.device)
+        if workspace is None:
+            workspace, nbytes = self._workspace(F, X.device)
+        else:
+            nbytes = workspace.numel() * workspace.element_size()
+        with torch.cuda.device(X.device):
+            _lib.check(_lib.lib().hg_aggr_fused_f32(
+                self._h, F, _ptr(csrptr_t), _ptr(colind_t), _ptr(X), _ptr(degE), _ptr(degV), _ptr(W),
+                _ptr(Y), _ptr(workspace), nbytes, _lib.VARIANTS[variant], _stream_handle(X.device)))
+        return Y
+
+    def gather_rows(self, hop, csrptr_t, colind_t, src, scaleA=None, scaleB=None):
+        """One hop: hop 0 = H^T src (rows = hyperedges), hop 1 = H src."""
+        _check_feat(src, "src")
+        F = src.shape[1]
+        nrows = self.M if hop == 0 else self.N
+        dst = torch.empty((nrows, F), dtype=torch.float32, device=src.device)
+        workspace, nbytes = self._workspace(F, src.device)
+        with torch.cuda.device(src.device):
+            _lib.check(_lib.lib().hg_gather_rows_f32(
+                self._h, hop, F, _ptr(csrptr_t), _ptr(colind_t), _ptr(src), _ptr(scaleA), _ptr(scaleB),
+                _ptr(dst), _ptr(workspace), nbytes, _stream_handle(src.device)))
+        return dst
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def _check_index(t, name):
+    # reference: assertTensor(..., torch::kInt32), hgnnaggr_cuda.cu:8-12 -- but raising, not aborting
+    if not isinstance(t, torch.Tensor) or t.dtype != torch.int32:
+        raise TypeError("%s must be an int32 tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s must be on a GPU (no CPU fallback in this backend)" % name)
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)
+
+
+def _check_feat(t, name, device=None):
+    if not isinstance(t, torch.Tensor) or t.dtype != torch.float32:
+        raise TypeError("%s must be a float32 tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s must be on a GPU (no CPU fallback in this backend)" % name)
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)
+    if device is not None and t.device != device:
+        raise RuntimeError("%s is on %s, expected %s" % (name, t.device, device))
+
+
+# ------------------------------------------------------------------ plan cache
+_CACHE = collections.OrderedDict()
+_CACHE_LOCK = threading.Lock()
+_CACHE_MAX = 32
+_DEFAULT_OPTS = None
+
+
+def set_default_opts(opts):
+    """Plan options used by plans created through the cache; clears the cache."""
+    global _DEFAULT_OPTS
+    with _CACHE_LOCK:
+        _DEFAULT_OPTS = opts
+        _CACHE.clear()
+
+
+def cached_plan(N, csrptr_t, colind_t):
+    """Plan for the hypergraph held in these two device tensors.  The key pins
+    storage address, length, device and torch's in-place version counter; the
+    entry keeps the tensors alive so an address cannot be recycled under it."""
+    key = (N, csrptr_t.data_ptr(), csrptr_t.numel(), csrptr_t._version,
+           colind_t.data_ptr(), colind_t.numel(), colind_t._version, str(csrptr_t.device))
+    with _CACHE_LOCK:
+        hit = _CACHE.get(key)
+        if hit is not None:
+            _CACHE.move_to_end(key)
+            return hit[0]
+    plan = Plan.from_tensors(N, csrptr_t, colind_t, _DEFAULT_OPTS)
+    with _CACHE_LOCK:
+        _CACHE[key] = (plan, csrptr_t, colind_t)
+        while len(_CACHE) > _CACHE_MAX:
+            _CACHE.popitem(last=False)
+    return plan
+
+
+def clear_plan_cache():
+    with _CACHE_LOCK:
+        _CACHE.clear()

@@ -1,0 +1,190 @@
+/*
+ * hg_aggr.h -- C ABI of libhgaggr.so, the MI355X (gfx950) backend for the fused
+ * vertex -> hyperedge -> vertex aggregation of HGNNConv / UniGNNConv.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch types.  It
+ * is what the reference's operator layer binds instead of its CUDA launchers.
+ * Each entry point cites the reference interface it replaces (paths relative
+ * to the reference tree).  INTEGRATION.md shows the binding stubs.
+ *
+ * Conventions (reference: HyperGsys/include/util/check.cuh:11-12):
+ *   Index = int32, DType = float32, feature matrices row-major [rows, F].
+ *   H is the N x M vertex-by-hyperedge incidence matrix; the caller supplies
+ *   H_T in CSR: csrptr_t[M+1], colind_t[nnz] (row = hyperedge, entries = member
+ *   vertices), exactly the `H_T_csrptr` / `H_T_colind` tensors of
+ *   HyperGsys/hypergraph.py:63-70.
+ *
+ * All device pointers must belong to the current HIP device.  Every function
+ * returns HG_OK or a negative hg_status; nothing aborts, nothing throws.
+ * hg_last_error() gives a thread-local message for the last failure.
+ * Calls that take a stream only enqueue work on it; they do not synchronise.
+ */
+#ifndef HG_AGGR_H
+#define HG_AGGR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HG_AGGR_VERSION 100 /* major*10000 + minor*100 + patch */
+
+#if defined(__GNUC__)
+#define HG_API __attribute__((visibility("default")))
+#else
+#define HG_API
+#endif
+
+typedef enum hg_status {
+  HG_OK = 0,
+  HG_ERR_INVALID = -1,     /* bad argument (null pointer, negative size, bad CSR) */
+  HG_ERR_NOMEM = -2,       /* host or device allocation failed */
+  HG_ERR_HIP = -3,         /* a HIP runtime call or kernel launch failed */
+  HG_ERR_WORKSPACE = -4,   /* caller workspace smaller than hg_plan_workspace_bytes */
+  HG_ERR_UNSUPPORTED = -5  /* combination not implemented */
+} hg_status;
+
+typedef void *hg_stream_t; /* a hipStream_t; NULL = the legacy default stream */
+typedef struct hg_plan hg_plan;
+
+/* Kernel family used by hg_aggr_fused_f32. */
+typedef enum hg_variant {
+  HG_VARIANT_AUTO = 0,
+  /* Atomic-free two-phase pull: Xe = S_e . (H^T X) over H_T CSR, then
+   * Y = S_v . (H Xe) over H CSR.  Deterministic; bit-exact with the CPU
+   * reference order for every row of at most `short_max` entries. */
+  HG_VARIANT_PULL = 1,
+  /* The reference's scheme (HGNNAggr_forward_kernel, hgnnaggr_cuda.cu:14-47):
+   * hyperedge partial sum kept in registers, scattered with fp32 atomics. */
+  HG_VARIANT_PUSH_ATOMIC = 2
+} hg_variant;
+
+typedef struct hg_plan_opts {
+  int32_t short_max;  /* rows longer than this are cut out as wave tasks (default 32) */
+  int32_t split_len;  /* a wave task covers at most this many entries (default 512)   */
+  int32_t panel_rows; /* rows per row-panel workgroup (default 128)                   */
+  int32_t panel_nnz;  /* index entries staged in LDS per panel (default 1024)         */
+  int32_t flags;      /* HG_PLAN_* bits                                              */
+} hg_plan_opts;
+
+#define HG_PLAN_HOST_ONLY 1 /* build the schedule on the host, upload nothing (tests) */
+#define HG_PLAN_NO_XCD_REMAP 2 /* keep blockIdx -> panel identity mapping */
+
+typedef struct hg_plan_info {
+  int32_t N, M;
+  int64_t nnz;
+  int32_t short_max, split_len, panel_rows, panel_nnz, flags;
+  /* hop 1 walks H_T (rows = hyperedges), hop 2 walks H (rows = vertices) */
+  int32_t panels[2];   /* row panels                                   */
+  int32_t tasks[2];    /* wave tasks for rows longer than short_max    */
+  int32_t partials[2]; /* partial-sum slots of rows split over tasks   */
+  int32_t fixups[2];   /* rows whose partials are summed in a 2nd pass */
+  int32_t max_len[2];  /* longest row of each CSR                      */
+  int64_t device_bytes; /* device memory held by the plan              */
+} hg_plan_info;
+
+HG_API int hg_version(void);
+HG_API const char *hg_last_error(void);
+HG_API const char *hg_status_string(int status);
+
+/* ---- scheduler, reference-compatible ------------------------------------
+ * Replaces balance_schedule (HyperGsys/balancer.py:4-33) and its C++ twin
+ * hgnn_ef_full_balance_cpu (include/taskbalancer/balancer_kernel.cuh:229-259):
+ * hyperedge r with n_r members is cut into w = ceil(n_r/ngs) partitions and
+ * w*w (read j, write i) tasks, i outer / j inner; `key` holds the partition
+ * starts plus a trailing nnz sentinel.  Host arrays in, host arrays out.
+ * Two-call protocol: pass key == NULL to get *n_key / *n_group, then call
+ * again with arrays of those lengths.  HG_ERR_INVALID when nnz == 0 (the
+ * reference raises IndexError there). */
+HG_API int hg_balance_schedule(int32_t nrow, int32_t ngs, const int32_t *csrptr_host,
+                        int64_t *n_key, int64_t *n_group, int32_t *key,
+                        int32_t *row, int32_t *group_st, int32_t *group_ed);
+
+/* ---- plan ------------------------------------------------------------------
+ * The plan is this backend's own schedule (what hgnn_balancer,
+ * include/taskbalancer/balancer.cuh:189-275, is to the reference kernels): it
+ * derives H in CSR (vertex -> incident hyperedges, ascending) from H_T and
+ * cuts both CSRs into row panels and wave tasks for 64-lane wavefronts.  It
+ * depends only on the sparsity structure; build once per hypergraph, reuse for
+ * every feature width and every call.  opts may be NULL (defaults). */
+HG_API int hg_plan_create_host(hg_plan **out, int32_t N, int32_t M,
+                        const int32_t *csrptr_t_host,
+                        const int32_t *colind_t_host,
+                        const hg_plan_opts *opts);
+/* Same, from device arrays (copies them to the host on `stream`, synchronises
+ * that stream once).  Not capturable into a hipGraph. */
+HG_API int hg_plan_create_device(hg_plan **out, int32_t N, int32_t M, int64_t nnz,
+                          const int32_t *csrptr_t_dev,
+                          const int32_t *colind_t_dev,
+                          const hg_plan_opts *opts, hg_stream_t stream);
+HG_API void hg_plan_destroy(hg_plan *plan);
+HG_API int hg_plan_get_info(const hg_plan *plan, hg_plan_info *info);
+/* Host copy of the derived H CSR (tests / CLI): ptr_v[N+1], ind_v[nnz]. */
+HG_API int hg_plan_get_vertex_csr(const hg_plan *plan, int32_t *ptr_v_host,
+                           int32_t *ind_v_host);
+/* Device pointers of the derived H CSR (valid for the plan's lifetime). */
+HG_API int hg_plan_get_vertex_csr_device(const hg_plan *plan, const int32_t **ptr_v_dev,
+                                  const int32_t **ind_v_dev);
+/* Host copy of one hop's schedule as int32 quadruples (tests, tools): panels
+ * {row0, nrows, nnz0, nnz_cnt}, tasks {row, beg, end, slot}, fixups {row,
+ * first_slot, count, 0}; sizes from hg_plan_get_info.  Pointers may be NULL. */
+HG_API int hg_plan_get_schedule(const hg_plan *plan, int32_t hop, int32_t *panels,
+                                int32_t *tasks, int32_t *fixups);
+/* Bytes of scratch hg_aggr_fused_f32 needs for feature width F (the M x F
+ * hyperedge feature matrix plus partial-sum slots), a multiple of 256. */
+HG_API size_t hg_plan_workspace_bytes(const hg_plan *plan, int32_t F);
+
+/* ---- the hot path ------------------------------------------------------------
+ * Y[v,:] = degV[v] * sum_{e contains v} ( degE[e] * W[e] * sum_{u in e} X[u,:] )
+ *
+ * Replaces hgnnaggr_fp_cuda (source/hgnnaggr/hgnnaggr_cuda.cu:350-406),
+ * unignnaggrdeg / unignnaggr launchers (source/unignnaggr/unignnaggr_cuda.cu:
+ * 392-488) and HyperGAggr_device (include/hgnnAgg.cuh:985-1038).
+ *   degE, W : [M] or NULL (factor 1);  degV : [N] or NULL.
+ *     hgnnaggr      -> degE, degV, W      unignnaggrdeg -> degE, degV, W = NULL
+ *     unignnaggr / aggr_proto kernels -> all three NULL
+ *   Arithmetic order is the reference test's (test/hgnn_test.py:56-63):
+ *     Xe = ((sum X) * degE) * W ;  Y = (sum Xe) * degV.
+ *   Y is fully overwritten (no pre-zeroing needed); inputs are not modified.
+ *   workspace: device scratch of at least hg_plan_workspace_bytes(plan, F),
+ *   256-byte aligned, private to this call until it completes on `stream`.
+ *   csrptr_t / colind_t must be the arrays the plan was built from. */
+HG_API int hg_aggr_fused_f32(const hg_plan *plan, int32_t F,
+                      const int32_t *csrptr_t, const int32_t *colind_t,
+                      const float *X, const float *degE, const float *degV,
+                      const float *W, float *Y, void *workspace,
+                      size_t workspace_bytes, int32_t variant,
+                      hg_stream_t stream);
+
+/* One hop only (CSR times dense with unit values, optional row scales):
+ *   dst[r,:] = scaleB[r] * scaleA[r] * sum_{p in row r} src[ind[p],:]
+ * hop = 0 walks H_T (nrows = M, src has N rows), hop = 1 walks the derived H
+ * (nrows = N, src has M rows).  The two-step comparator and tests use it; it
+ * is the own-kernel counterpart of csrspmm_cusparse (include/spmm/spmm.cuh:
+ * 22-77). */
+HG_API int hg_gather_rows_f32(const hg_plan *plan, int32_t hop, int32_t F,
+                       const int32_t *csrptr_t, const int32_t *colind_t,
+                       const float *src, const float *scaleA,
+                       const float *scaleB, float *dst, void *workspace,
+                       size_t workspace_bytes, hg_stream_t stream);
+
+/* The reference's kernel driven by the reference's schedule tensors
+ * (HGNNAggr_forward_kernel(+_sf), hgnnaggr_cuda.cu:14-84; unweighted twins
+ * hgnnAgg.cuh:33-53, 98-167): task g reads partition group_st[g] and scatters
+ * to partition group_ed[g] of hyperedge group_row[g] with fp32 atomics.  Pass
+ * group_key == NULL for one task per hyperedge (needs csrptr_t).  Y is zeroed
+ * on `stream` first (the reference's torch::zeros, hgnnaggr_cuda.cu:374). */
+HG_API int hg_aggr_push_groups_f32(int32_t N, int32_t M, int32_t F, int64_t n_group,
+                            const int32_t *group_key, const int32_t *group_row,
+                            const int32_t *group_st, const int32_t *group_ed,
+                            const int32_t *csrptr_t, const int32_t *colind_t,
+                            const float *X, const float *degE,
+                            const float *degV, const float *W, float *Y,
+                            hg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HG_AGGR_H */

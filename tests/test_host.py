@@ -1,0 +1,183 @@
+"""CPU-only: the C-ABI library loads, exports every declared symbol, and its
+host logic (reference-compatible scheduler, plan builder) is right.  No device
+compute is called here.  (-m "not gpu")"""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, golden_files, vertex_csr
+from hypergef_amd import synth
+
+
+def test_library_exports_every_declared_symbol(hg):
+    from hypergef_amd import _lib
+    L = _lib.lib()
+    header = open(os.path.join(ROOT, "include", "hg_aggr.h")).read()
+    declared = set(re.findall(r"HG_API[^;(]*?\b(hg_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.hg_version() == 100
+    assert L.hg_status_string(-4) == b"workspace too small"
+
+
+@pytest.mark.parametrize("fname", golden_files("balancer_"))
+def test_native_balance_schedule_matches_reference_golden(hg, fname):
+    g = np.load(os.path.join(GOLDEN, fname))
+    bs = hg.balance_schedule(int(g["ngs"]), g["csrptr"])
+    np.testing.assert_array_equal(bs.balan_key, g["balan_key"])
+    np.testing.assert_array_equal(bs.balan_row, g["balan_row"])
+    np.testing.assert_array_equal(bs.group_st, g["group_st"])
+    np.testing.assert_array_equal(bs.group_ed, g["group_ed"])
+    assert bs.balan_key.dtype == np.int32 and bs.nrow == g["csrptr"].shape[0] - 1
+
+
+def test_native_balance_schedule_accepts_torch_and_rejects_empty(hg):
+    import torch
+    bs = hg.balance_schedule(2, torch.tensor([0, 3, 3, 8, 9], dtype=torch.int32))
+    assert bs.balan_key.tolist() == [0, 2, 3, 5, 7, 8, 9]
+    with pytest.raises(IndexError):
+        hg.balance_schedule(4, np.array([0, 0, 0], np.int32))
+
+
+def test_balance_schedule_no_float32_rounding(hg):
+    """Defect D7: indices above 2**24 must survive (reference rounds them)."""
+    base = (1 << 24) + 1
+    csrptr = np.array([0, base, base + 3], np.int64).astype(np.int32)
+    bs = hg.balance_schedule(1 << 30, csrptr)
+    assert bs.balan_key.tolist() == [0, base, base + 3]
+
+
+def _emulate(plan_sched, ptr, ind, src, scaleA, scaleB, F):
+    """numpy float32 emulation of gather_rows_kernel + fixup semantics."""
+    nrows = ptr.shape[0] - 1
+    dst = np.full((nrows, F), np.nan, np.float32)
+    written = np.zeros(nrows, np.int32)
+
+    def scale(r, acc):
+        if scaleA is not None:
+            acc = acc * scaleA[r]
+        if scaleB is not None:
+            acc = acc * scaleB[r]
+        return acc
+
+    for row0, n, nnz0, cnt in plan_sched["panels"]:
+        assert ptr[row0] == nnz0 and ptr[row0 + n] - nnz0 == cnt
+        for r in range(row0, row0 + n):
+            acc = np.zeros(F, np.float32)
+            for p in range(ptr[r], ptr[r + 1]):
+                acc = acc + src[ind[p]]
+            dst[r] = scale(r, acc) if ptr[r + 1] > ptr[r] else acc
+            written[r] += 1
+    nslots = int(plan_sched["fixups"][:, 2].sum()) if len(plan_sched["fixups"]) else 0
+    partial = np.full((nslots, F), np.nan, np.float32)
+    for row, beg, end, slot in plan_sched["tasks"]:
+        assert ptr[row] <= beg < end <= ptr[row + 1]
+        acc = src[ind[beg:end]].astype(np.float64).sum(0).astype(np.float32)
+        if slot < 0:
+            assert beg == ptr[row] and end == ptr[row + 1]
+            dst[row] = scale(row, acc)
+            written[row] += 1
+        else:
+            partial[slot] = acc
+    for row, first, count, _ in plan_sched["fixups"]:
+        acc = np.zeros(F, np.float32)
+        for k in range(count):
+            acc = acc + partial[first + k]
+        dst[row] = scale(row, acc)
+        written[row] += 1
+    assert np.all(written == 1), "every row must be produced exactly once"
+    return dst
+
+
+@pytest.mark.parametrize("case", ["cora", "pubmed", "ragged_split", "tiny_panels"])
+def test_plan_schedule_covers_and_reproduces_oracle(hg, oracle, case):
+    from hypergef_amd import plan as planmod
+    if case == "cora":
+        inc, opts = synth.cora_shape(), planmod.make_opts(host_only=True)
+    elif case == "pubmed":
+        inc, opts = synth.pubmed_shape(), planmod.make_opts(host_only=True)
+    elif case == "ragged_split":  # long rows cut into several tasks + fixups, empty hyperedges
+        inc = synth.random_incidence(400, 150, 14.0, seed=4, empty_frac=0.15)
+        opts = planmod.make_opts(short_max=6, split_len=8, panel_rows=16, panel_nnz=32, host_only=True)
+    else:
+        inc = synth.random_incidence(97, 211, 2.5, seed=8, empty_frac=0.3)
+        opts = planmod.make_opts(short_max=4, split_len=4, panel_rows=3, panel_nnz=7, host_only=True)
+    plan = planmod.Plan.from_host(inc.N, inc.M, inc.csrptr, inc.colind, opts)
+    H_ptr, H_ind = vertex_csr(inc, oracle)
+    pv, iv = plan.vertex_csr()
+    assert np.array_equal(pv, H_ptr) and np.array_equal(iv, H_ind)
+
+    F = 3
+    rng = np.random.default_rng(1)
+    X = rng.standard_normal((inc.N, F)).astype(np.float32)
+    degE, degV = oracle.degrees(inc.N, inc.M, inc.csrptr, inc.colind)
+    W = (rng.random(inc.M) + 0.5).astype(np.float32)
+    s0, s1 = plan.schedule(0), plan.schedule(1)
+    info = plan.info
+    for hop, s in ((0, s0), (1, s1)):
+        lens = np.diff(inc.csrptr if hop == 0 else H_ptr)
+        assert info["max_len"][hop] == (lens.max() if len(lens) else 0)
+        if len(s["panels"]):
+            assert s["panels"][:, 1].max() <= info["panel_rows"]
+            assert s["panels"][:, 3].max() <= info["panel_nnz"]
+        if len(s["tasks"]):
+            tl = s["tasks"][:, 2] - s["tasks"][:, 1]
+            assert tl.max() <= info["split_len"] and np.all(np.diff(tl) <= 0)  # longest first
+        assert info["partials"][hop] == (s["fixups"][:, 2].sum() if len(s["fixups"]) else 0)
+    Xe = _emulate(s0, inc.csrptr, inc.colind, X, degE.ravel(), W, F)
+    Y = _emulate(s1, H_ptr, H_ind, Xe, degV.ravel(), None, F)
+    Yref, Xe_ref = oracle.hgnn_check(inc.N, inc.M, F, H_ptr, H_ind, inc.csrptr, inc.colind, X,
+                                     degE, degV, W, return_xe=True)
+    live = np.diff(inc.csrptr) > 0
+    np.testing.assert_allclose(Xe[live], Xe_ref[live], rtol=1e-5, atol=1e-6)
+    assert np.all(Xe[~live] == 0)  # empty hyperedges stay exactly 0 even though degE is inf
+    np.testing.assert_allclose(Y, Yref, rtol=1e-5, atol=1e-6)
+    short = np.diff(inc.csrptr) <= info["short_max"]
+    assert np.array_equal(Xe[short & live], Xe_ref[short & live])  # panel rows are bit-exact
+
+
+def test_plan_rejects_bad_input(hg):
+    from hypergef_amd import _lib, plan as planmod
+    ho = planmod.make_opts(host_only=True)
+    with pytest.raises(_lib.HgError):  # column index out of range
+        planmod.Plan.from_host(3, 2, np.array([0, 1, 2], np.int32), np.array([0, 3], np.int32), ho)
+    with pytest.raises(_lib.HgError):  # non-monotone row pointer
+        planmod.Plan.from_host(3, 2, np.array([0, 2, 1], np.int32), np.array([0], np.int32), ho)
+    with pytest.raises(_lib.HgError):  # short_max > panel_nnz
+        planmod.Plan.from_host(3, 1, np.array([0, 1], np.int32), np.array([0], np.int32),
+                               planmod.make_opts(short_max=64, panel_nnz=32, host_only=True))
+    with pytest.raises(ValueError):
+        planmod.Plan.from_host(3, 2, np.array([0, 1], np.int32), np.array([0], np.int32), ho)
+
+
+def test_host_only_plan_refuses_to_launch(hg):
+    from hypergef_amd import _lib, plan as planmod
+    inc = synth.cora_shape()
+    plan = planmod.Plan.from_host(inc.N, inc.M, inc.csrptr, inc.colind, planmod.make_opts(host_only=True))
+    ws = plan.workspace_bytes(32)
+    assert ws >= inc.M * 32 * 4 and ws % 256 == 0
+    rc = _lib.lib().hg_aggr_fused_f32(plan._h, 32, None, None, None, None, None, None, None, None, 0, 0, None)
+    assert rc == -1  # HG_ERR_INVALID, never a crash
+
+
+def test_degenerate_plans(hg):
+    from hypergef_amd import plan as planmod
+    ho = planmod.make_opts(host_only=True)
+    p = planmod.Plan.from_host(5, 0, np.array([0], np.int32), np.zeros(0, np.int32), ho)
+    assert p.info["panels"] == [0, 1] and p.nnz == 0
+    p = planmod.Plan.from_host(4, 3, np.array([0, 0, 0, 0], np.int32), np.zeros(0, np.int32), ho)
+    assert p.info["panels"] == [1, 1] and p.info["tasks"] == [0, 0]
+
+
+def test_ops_refuse_cpu_tensors(hg):
+    """The product path never computes on the CPU."""
+    import torch
+    inc = synth.cora_shape()
+    x = torch.zeros(inc.N, 4)
+    ptr, ind = torch.from_numpy(inc.csrptr), torch.from_numpy(inc.colind)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        hg.ops.unignnaggr(ptr, ptr, ptr, ptr, ptr, ind, x)
