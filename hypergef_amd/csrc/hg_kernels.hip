@@ -8,6 +8,8 @@
 // dwordx4 = one 128-byte line per row, 8 rows per wave instruction).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "hg_kernels.h"
 
 namespace hg {
@@ -48,7 +50,7 @@ template <> struct Vec<4> {
 // loads, then every LPR-lane group walks a contiguous run of the panel's rows as
 // one flat entry stream, U row loads in flight, adding in CSR order (so short
 // rows reproduce the CPU reference's summation order exactly).
-template <int LPR, int VEC, int U>
+template <int LPR, int VEC, int U, bool PIPE>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const GatherArgs a) {
   constexpr int G = 64 / LPR;    // row groups per wave
   constexpr int NG = 256 / LPR;  // row groups per workgroup
@@ -134,18 +136,19 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const GatherArgs a) {
   const int stop = sptr[re];
   int row_end = sptr[r + 1];
   V acc = V::zero();
-  while (pos < stop) {
-    const int n = min(U, stop - pos);
-    V v[U];
+
+  auto issue = [&](int p0, int n, V(&v)[U]) {
 #pragma unroll
     for (int k = 0; k < U; k++) {
-      const int64_t idx = sind[pos + min(k, n - 1)];
+      const int64_t idx = sind[p0 + min(k, n - 1)];
       v[k] = col_ok ? V::load(a.src + idx * F + col) : V::zero();
     }
+  };
+  auto consume = [&](int p0, int n, const V(&v)[U]) {
 #pragma unroll
     for (int k = 0; k < U; k++) {
       if (k < n) {
-        while (row_end <= pos + k) {
+        while (row_end <= p0 + k) {
           flush(r, acc);
           acc = V::zero();
           r++;
@@ -154,7 +157,32 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const GatherArgs a) {
         acc.add(v[k]);
       }
     }
-    pos += n;
+  };
+
+  if constexpr (PIPE) {
+    // two batches in flight: the next batch's loads are issued before the
+    // current one is consumed, so the wave always has row loads outstanding
+    V cur[U];
+    int ncur = min(U, stop - pos);
+    if (ncur > 0) issue(pos, ncur, cur);
+    while (ncur > 0) {
+      V nxt[U];
+      const int nn = min(U, stop - pos - ncur);
+      if (nn > 0) issue(pos + ncur, nn, nxt);
+      consume(pos, ncur, cur);
+      pos += ncur;
+      ncur = nn;
+#pragma unroll
+      for (int k = 0; k < U; k++) cur[k] = nxt[k];
+    }
+  } else {
+    while (pos < stop) {
+      const int n = min(U, stop - pos);
+      V v[U];
+      issue(pos, n, v);
+      consume(pos, n, v);
+      pos += n;
+    }
   }
   while (r < re) {
     flush(r, acc);
@@ -225,16 +253,37 @@ static inline int next_pow2(int x) {
   return p;
 }
 
+struct Tuning {
+  int unroll = 4;
+  int pipe = 0;
+};
+// Experiment knobs (HG_UNROLL = 4|8, HG_PIPE = 0|1), read once.
+static const Tuning &tuning() {
+  static const Tuning t = [] {
+    Tuning x;
+    if (const char *e = getenv("HG_UNROLL")) x.unroll = atoi(e) == 8 ? 8 : 4;
+    if (const char *e = getenv("HG_PIPE")) x.pipe = atoi(e) != 0;
+    return x;
+  }();
+  return t;
+}
+
 template <int LPR, int VEC>
 static hipError_t launch_gather_t(const GatherArgs &a, int nfix, const Fixup *fixups,
                                   hipStream_t stream) {
-  constexpr int U = 4;
   const int col_tiles = (a.F + LPR * VEC - 1) / (LPR * VEC);
   const int nblocks = a.n_task_blocks + a.npanels;
   if (nblocks > 0) {
     const size_t lds = (size_t)(3 * a.panel_rows + 1 + a.panel_nnz) * sizeof(int32_t);
-    hipLaunchKernelGGL((gather_rows_kernel<LPR, VEC, U>), dim3(nblocks, col_tiles), dim3(256), lds,
-                       stream, a);
+    const dim3 grid(nblocks, col_tiles), block(256);
+    const Tuning &t = tuning();
+    if (t.unroll == 8) {
+      if (t.pipe) hipLaunchKernelGGL((gather_rows_kernel<LPR, VEC, 8, true>), grid, block, lds, stream, a);
+      else hipLaunchKernelGGL((gather_rows_kernel<LPR, VEC, 8, false>), grid, block, lds, stream, a);
+    } else {
+      if (t.pipe) hipLaunchKernelGGL((gather_rows_kernel<LPR, VEC, 4, true>), grid, block, lds, stream, a);
+      else hipLaunchKernelGGL((gather_rows_kernel<LPR, VEC, 4, false>), grid, block, lds, stream, a);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }

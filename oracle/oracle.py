@@ -209,15 +209,15 @@ def num_threads():
 def degrees(N, M, HT_ptr, HT_ind):
     """hypergraph.py:34-49: degV = rowsum(H)^-1/2 with inf -> 1, shape [N,1];
     degE = colsum(H)^-1, shape [M,1], NO inf guard (float32, torch.pow)."""
+    import torch  # the reference computes these with torch.pow on CPU tensors
     HT_ptr = np.asarray(HT_ptr, np.int64)
     HT_ind = np.asarray(HT_ind, np.int64)
-    cntV = np.bincount(HT_ind, minlength=N).astype(np.float32)
-    cntE = np.diff(HT_ptr).astype(np.float32)
-    with np.errstate(divide="ignore"):
-        degV = np.power(cntV, np.float32(-0.5)).astype(np.float32)
-        degE = np.power(cntE, np.float32(-1.0)).astype(np.float32)
-    degV[np.isinf(degV)] = 1
-    return degE.reshape(M, 1), degV.reshape(N, 1)
+    cntV = torch.from_numpy(np.bincount(HT_ind, minlength=N).astype(np.float64)).float()
+    cntE = torch.from_numpy(np.diff(HT_ptr).astype(np.float64)).float()
+    degV = cntV.pow(-0.5)
+    degE = cntE.pow(-1)
+    degV[torch.isinf(degV)] = 1
+    return degE.reshape(M, 1).numpy(), degV.reshape(N, 1).numpy()
 
 
 def read_mtx(path):
