@@ -14,10 +14,26 @@ import torch
 from hypergef_amd import plan as planmod, synth
 
 
-def timeit(fn, iters):
+def timeit(fn, iters, graph=True):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
+    if graph:  # replay a captured batch of launches: no host overhead between kernels
+        reps = max(1, min(iters, 50))
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(reps):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        outer = max(1, iters // reps)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(outer):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / (outer * reps) * 1e-3
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
@@ -51,8 +67,15 @@ def main():
         ws = torch.empty(max(plan.workspace_bytes(F), 256), dtype=torch.uint8, device=dev)
         Xe = plan.gather_rows(0, ptr, ind, X)
         it = max(a.iters, min(2000, int(a.iters * 1024 / K)))
-        t1 = timeit(lambda: plan.gather_rows(0, ptr, ind, X), it)
-        t2 = timeit(lambda: plan.gather_rows(1, ptr, ind, Xe), it)
+        Xe_out = torch.empty(inc.M, F, device=dev)
+        from hypergef_amd import _lib
+        import ctypes
+        def hop(h, src, dst):
+            _lib.check(_lib.lib().hg_gather_rows_f32(plan._h, h, F, planmod._ptr(ptr), planmod._ptr(ind),
+                       planmod._ptr(src), None, None, planmod._ptr(dst), planmod._ptr(ws), ws.numel(),
+                       planmod._stream_handle(X.device)))
+        t1 = timeit(lambda: hop(0, X, Xe_out), it)
+        t2 = timeit(lambda: hop(1, Xe, Y), it)
         tf = timeit(lambda: plan.aggregate(ptr, ind, X, out=Y, workspace=ws), it)
         NF, MF, nz = inc.N * F * 4, inc.M * F * 4, inc.nnz * 4
         b1 = NF + MF + nz + inc.M * 4      # read X, write Xe, indices, ptr
