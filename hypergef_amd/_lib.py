@@ -13,16 +13,18 @@ HG_OK = 0
 HG_VARIANT_AUTO = 0
 HG_VARIANT_PULL = 1
 HG_VARIANT_PUSH_ATOMIC = 2
+HG_VARIANT_FUSED = 3
 HG_PLAN_HOST_ONLY = 1
 HG_PLAN_NO_XCD_REMAP = 2
 
-VARIANTS = {"auto": HG_VARIANT_AUTO, "pull": HG_VARIANT_PULL, "push_atomic": HG_VARIANT_PUSH_ATOMIC}
+VARIANTS = {"auto": HG_VARIANT_AUTO, "pull": HG_VARIANT_PULL, "push_atomic": HG_VARIANT_PUSH_ATOMIC,
+            "fused": HG_VARIANT_FUSED}
 
 # every symbol include/hg_aggr.h declares (tests check the library exports all)
 SYMBOLS = (
     "hg_version", "hg_last_error", "hg_status_string", "hg_balance_schedule",
     "hg_plan_create_host", "hg_plan_create_device", "hg_plan_destroy", "hg_plan_get_info",
-    "hg_plan_get_vertex_csr", "hg_plan_get_vertex_csr_device", "hg_plan_get_schedule",
+    "hg_plan_get_vertex_csr", "hg_plan_get_vertex_csr_device", "hg_plan_get_schedule", "hg_plan_prepare",
     "hg_plan_workspace_bytes",
     "hg_aggr_fused_f32", "hg_gather_rows_f32", "hg_aggr_push_groups_f32",
 )
@@ -37,7 +39,17 @@ class HgError(RuntimeError):
 class PlanOpts(ctypes.Structure):
     _fields_ = [("short_max", ctypes.c_int32), ("split_len", ctypes.c_int32),
                 ("panel_rows", ctypes.c_int32), ("panel_nnz", ctypes.c_int32),
-                ("flags", ctypes.c_int32)]
+                ("flags", ctypes.c_int32), ("t_big", ctypes.c_int32),
+                ("fused_tile_bytes", ctypes.c_int32)]
+
+
+class FusedInfo(ctypes.Structure):
+    _fields_ = [("cap", ctypes.c_int32), ("t_big", ctypes.c_int32), ("vdeg_max", ctypes.c_int32),
+                ("panels", ctypes.c_int32), ("n_mat", ctypes.c_int32), ("n_hub", ctypes.c_int32),
+                ("slots", ctypes.c_int64), ("member_entries", ctypes.c_int64)]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
 
 
 class PlanInfo(ctypes.Structure):
@@ -93,6 +105,8 @@ def lib():
     L.hg_plan_get_vertex_csr_device.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp)]
     L.hg_plan_get_schedule.restype = ctypes.c_int
     L.hg_plan_get_schedule.argtypes = [vp, i32, vp, vp, vp]
+    L.hg_plan_prepare.restype = ctypes.c_int
+    L.hg_plan_prepare.argtypes = [vp, i32, ctypes.POINTER(FusedInfo)]
     L.hg_plan_workspace_bytes.restype = sz
     L.hg_plan_workspace_bytes.argtypes = [vp, i32]
     L.hg_aggr_fused_f32.restype = ctypes.c_int

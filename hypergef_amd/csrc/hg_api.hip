@@ -5,6 +5,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <new>
 #include <string>
 
@@ -34,10 +35,12 @@ int resolve_opts(const hg_plan_opts *in, hg::Opts &o) {
     if (in->panel_rows > 0) o.panel_rows = in->panel_rows;
     if (in->panel_nnz > 0) o.panel_nnz = in->panel_nnz;
     o.flags = in->flags;
+    if (in->t_big > 0) o.t_big = in->t_big;
+    if (in->fused_tile_bytes > 0) o.fused_tile_bytes = in->fused_tile_bytes;
   }
   if (o.short_max > o.panel_nnz || o.split_len < o.short_max || o.panel_rows > 4096 ||
-      o.panel_nnz > 16384) {
-    hg::set_error("hg_plan_opts: need short_max <= panel_nnz <= 16384, split_len >= short_max, panel_rows <= 4096");
+      o.panel_nnz > 16384 || o.fused_tile_bytes > 65536) {
+    hg::set_error("hg_plan_opts: need short_max <= panel_nnz <= 16384, split_len >= short_max, panel_rows <= 4096, fused_tile_bytes <= 65536");
     return HG_ERR_INVALID;
   }
   return HG_OK;
@@ -58,17 +61,101 @@ int upload(const std::vector<T> &h, T **d, int64_t &bytes) {
   return HG_OK;
 }
 
+int sched_upload(hg::Sched &s, int64_t &bytes) {
+  int rc;
+  if ((rc = upload(s.panels, &s.d_panels, bytes)) != HG_OK) return rc;
+  if ((rc = upload(s.tasks, &s.d_tasks, bytes)) != HG_OK) return rc;
+  return upload(s.fixups, &s.d_fixups, bytes);
+}
+
+void sched_free(hg::Sched &s) {
+  if (s.d_panels) (void)hipFree(s.d_panels);
+  if (s.d_tasks) (void)hipFree(s.d_tasks);
+  if (s.d_fixups) (void)hipFree(s.d_fixups);
+  s.d_panels = nullptr;
+  s.d_tasks = nullptr;
+  s.d_fixups = nullptr;
+}
+
 int plan_upload(hg_plan *p) {
   HG_HIP(hipGetDevice(&p->device));
   int rc;
   if ((rc = upload(p->ptr_v, &p->d_ptr_v, p->device_bytes)) != HG_OK) return rc;
   if ((rc = upload(p->ind_v, &p->d_ind_v, p->device_bytes)) != HG_OK) return rc;
-  for (int h = 0; h < 2; h++) {
-    hg::Sched &s = p->sched[h];
-    if ((rc = upload(s.panels, &s.d_panels, p->device_bytes)) != HG_OK) return rc;
-    if ((rc = upload(s.tasks, &s.d_tasks, p->device_bytes)) != HG_OK) return rc;
-    if ((rc = upload(s.fixups, &s.d_fixups, p->device_bytes)) != HG_OK) return rc;
+  for (int h = 0; h < 2; h++)
+    if ((rc = sched_upload(p->sched[h], p->device_bytes)) != HG_OK) return rc;
+  return HG_OK;
+}
+
+int fused_upload(hg::FusedSched &f, int64_t &bytes) {
+  int rc;
+#define UP(v, d) if ((rc = upload(f.v, &f.d, bytes)) != HG_OK) return rc
+  UP(panels, d_panels);
+  UP(soff, d_soff);
+  UP(pmem, d_pmem);
+  UP(slot_eid, d_slot_eid);
+  UP(vslot, d_vslot);
+  UP(mat_ptr, d_mat_ptr);
+  UP(mat_ind, d_mat_ind);
+  UP(mat_eid, d_mat_eid);
+  UP(hub_ptr, d_hub_ptr);
+  UP(hub_ind, d_hub_ind);
+  UP(hub_vid, d_hub_vid);
+#undef UP
+  if ((rc = sched_upload(f.mat_sched, bytes)) != HG_OK) return rc;
+  return sched_upload(f.hub_sched, bytes);
+}
+
+void fused_free(hg::FusedSched &f) {
+  void *ptrs[] = {f.d_panels, f.d_soff, f.d_pmem, f.d_slot_eid, f.d_vslot, f.d_mat_ptr,
+                  f.d_mat_ind, f.d_mat_eid, f.d_hub_ptr, f.d_hub_ind, f.d_hub_vid};
+  for (void *q : ptrs)
+    if (q) (void)hipFree(q);
+  sched_free(f.mat_sched);
+  sched_free(f.hub_sched);
+}
+
+int fused_cap(const hg_plan *p, int32_t F, bool vec4) {
+  const int row_bytes = hg::fused_tile_row_floats(F, vec4) * 4;
+  int cap = p->opts.fused_tile_bytes / row_bytes;
+  cap = std::max(16, std::min(256, cap));
+  int p2 = 16;
+  while (p2 * 2 <= cap) p2 *= 2;
+  return p2;
+}
+
+// The F-dependent part of the plan, built on first use (guarded by the plan's mutex).
+int get_fused(const hg_plan *cp, int32_t F, bool vec4, const hg::FusedSched **out) {
+  hg_plan *p = const_cast<hg_plan *>(cp);
+  const int cap = fused_cap(p, F, vec4);
+  std::lock_guard<std::mutex> lock(p->fused_mu);
+  auto it = p->fused.find(cap);
+  if (it == p->fused.end()) {
+    hg::FusedSched f;
+    try {
+      hg::build_fused(p->N, p->M, p->ptr_t.data(), p->ind_t.data(), p->ptr_v.data(), p->ind_v.data(),
+                      p->opts, cap, f);
+    } catch (const std::bad_alloc &) {
+      hg::set_error("fused schedule: host allocation failed");
+      return HG_ERR_NOMEM;
+    }
+    // the kernel's LDS carve-up trusts these bounds: check them before anything can launch
+    for (const hg::FPanel &pn : f.panels) {
+      const int32_t nvs = p->ptr_v[pn.row0 + pn.nrows] - p->ptr_v[pn.row0];
+      if (pn.nrows <= 0 || pn.nrows > f.rows_cap || pn.nslots > f.cap || pn.npm > f.mem_cap ||
+          nvs > f.vslot_cap || pn.row0 < 0 || pn.row0 + pn.nrows > p->N) {
+        hg::set_error("fused schedule: internal error, panel exceeds its LDS budget");
+        return HG_ERR_INVALID;
+      }
+    }
+    int rc = (p->opts.flags & HG_PLAN_HOST_ONLY) ? HG_OK : fused_upload(f, p->device_bytes);
+    if (rc != HG_OK) {
+      fused_free(f);
+      return rc;
+    }
+    it = p->fused.emplace(cap, std::move(f)).first;
   }
+  *out = &it->second;
   return HG_OK;
 }
 
@@ -88,11 +175,13 @@ Carve carve(const hg_plan *p, int32_t F) {
   return c;
 }
 
-int run_hop(const hg_plan *p, int hop, int32_t F, const int32_t *ptr, const int32_t *ind,
-            const float *src, const float *scaleA, const float *scaleB, float *dst,
-            float *partial, hipStream_t stream) {
-  const hg::Sched &s = p->sched[hop];
+int run_sched(const hg_plan *p, const hg::Sched &s, int32_t F, const int32_t *ptr,
+              const int32_t *ind, const float *src, const float *scaleA, const float *scaleB,
+              const int32_t *scale_map, const int32_t *dst_map, float *dst, float *partial,
+              hipStream_t stream) {
   hg::GatherArgs a;
+  a.scale_map = scale_map;
+  a.dst_map = dst_map;
   a.ptr = ptr;
   a.ind = ind;
   a.src = src;
@@ -113,6 +202,13 @@ int run_hop(const hg_plan *p, int hop, int32_t F, const int32_t *ptr, const int3
   hipError_t e = hg::launch_gather(a, (int)s.fixups.size(), s.d_fixups, vec4, stream);
   if (e != hipSuccess) return hip_fail("gather_rows launch", e);
   return HG_OK;
+}
+
+int run_hop(const hg_plan *p, int hop, int32_t F, const int32_t *ptr, const int32_t *ind,
+            const float *src, const float *scaleA, const float *scaleB, float *dst,
+            float *partial, hipStream_t stream) {
+  return run_sched(p, p->sched[hop], F, ptr, ind, src, scaleA, scaleB, nullptr, nullptr, dst, partial,
+                   stream);
 }
 
 int check_call(const hg_plan *plan, int32_t F, const void *workspace, size_t workspace_bytes) {
@@ -166,6 +262,8 @@ int plan_build(hg_plan **out, int32_t N, int32_t M, const int32_t *csrptr_t,
     p->M = M;
     p->nnz = csrptr_t[M];
     p->opts = o;
+    p->ptr_t.assign(csrptr_t, csrptr_t + M + 1);
+    p->ind_t.assign(colind_t, colind_t + p->nnz);
     hg::transpose_csr(M, N, csrptr_t, colind_t, p->ptr_v, p->ind_v);
     hg::build_sched(M, csrptr_t, o, p->sched[0]);
     hg::build_sched(N, p->ptr_v.data(), o, p->sched[1]);
@@ -227,11 +325,8 @@ void hg_plan_destroy(hg_plan *p) {
   if (!p) return;
   if (p->d_ptr_v) (void)hipFree(p->d_ptr_v);
   if (p->d_ind_v) (void)hipFree(p->d_ind_v);
-  for (int h = 0; h < 2; h++) {
-    if (p->sched[h].d_panels) (void)hipFree(p->sched[h].d_panels);
-    if (p->sched[h].d_tasks) (void)hipFree(p->sched[h].d_tasks);
-    if (p->sched[h].d_fixups) (void)hipFree(p->sched[h].d_fixups);
-  }
+  for (int h = 0; h < 2; h++) sched_free(p->sched[h]);
+  for (auto &kv : p->fused) fused_free(kv.second);
   delete p;
 }
 
@@ -292,6 +387,29 @@ int hg_plan_get_schedule(const hg_plan *p, int32_t hop, int32_t *panels, int32_t
   if (panels && !s.panels.empty()) std::memcpy(panels, s.panels.data(), s.panels.size() * sizeof(hg::Panel));
   if (tasks && !s.tasks.empty()) std::memcpy(tasks, s.tasks.data(), s.tasks.size() * sizeof(hg::Task));
   if (fixups && !s.fixups.empty()) std::memcpy(fixups, s.fixups.data(), s.fixups.size() * sizeof(hg::Fixup));
+  return HG_OK;
+}
+
+int hg_plan_prepare(const hg_plan *p, int32_t F, hg_fused_info *info) {
+  if (!p || F <= 0) {
+    hg::set_error("hg_plan_prepare: bad argument");
+    return HG_ERR_INVALID;
+  }
+  const hg::FusedSched *f = nullptr;
+  int rc = get_fused(p, F, F % 4 == 0, &f);
+  if (rc != HG_OK) return rc;
+  if (info) {
+    info->cap = f->cap;
+    info->t_big = f->t_big;
+    info->vdeg_max = f->vdeg_max;
+    info->panels = (int32_t)f->panels.size();
+    info->n_mat = f->n_mat;
+    info->n_hub = f->n_hub;
+    info->member_entries = f->pmem_entries;
+    int64_t slots = 0;
+    for (const auto &pn : f->panels) slots += pn.nslots;
+    info->slots = slots;
+  }
   return HG_OK;
 }
 
@@ -365,7 +483,7 @@ int hg_aggr_fused_f32(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
     return hg_aggr_push_groups_f32(plan->N, plan->M, F, plan->M, nullptr, nullptr, nullptr, nullptr,
                                    csrptr_t, colind_t, X, degE, degV, W, Y, stream);
   }
-  if (variant != HG_VARIANT_AUTO && variant != HG_VARIANT_PULL) {
+  if (variant != HG_VARIANT_AUTO && variant != HG_VARIANT_PULL && variant != HG_VARIANT_FUSED) {
     hg::set_error("hg_aggr_fused_f32: unknown variant");
     return HG_ERR_UNSUPPORTED;
   }
@@ -379,6 +497,47 @@ int hg_aggr_fused_f32(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
   const Carve c = carve(plan, F);
   char *ws = static_cast<char *>(workspace);
   float *Xe = reinterpret_cast<float *>(ws + c.xe);
+  if (variant == HG_VARIANT_FUSED) {
+    const bool vec4 = (F % 4 == 0) && aligned16(X) && aligned16(Y) && aligned16(Xe);
+    const hg::FusedSched *f = nullptr;
+    if ((rc = get_fused(plan, F, vec4, &f)) != HG_OK) return rc;
+    // (a) materialised hyperedges (long ones, and those of hub vertices): Xe_mat rows
+    if (f->n_mat > 0) {
+      rc = run_sched(plan, f->mat_sched, F, f->d_mat_ptr, f->d_mat_ind, X, degE, W, f->d_mat_eid,
+                     nullptr, Xe, reinterpret_cast<float *>(ws + c.part[0]), s);
+      if (rc != HG_OK) return rc;
+    }
+    // (b) hub vertices: plain row gathers over Xe_mat
+    if (f->n_hub > 0) {
+      rc = run_sched(plan, f->hub_sched, F, f->d_hub_ptr, f->d_hub_ind, Xe, degV, nullptr,
+                     f->d_hub_vid, f->d_hub_vid, Y, reinterpret_cast<float *>(ws + c.part[1]), s);
+      if (rc != HG_OK) return rc;
+    }
+    // (c) everything else: vertex panels with the hyperedge sums staged in LDS
+    hg::FusedArgs a;
+    a.panels = f->d_panels;
+    a.npanels = (int32_t)f->panels.size();
+    a.soff = f->d_soff;
+    a.pmem = f->d_pmem;
+    a.slot_eid = f->d_slot_eid;
+    a.vslot = f->d_vslot;
+    a.ptr_v = plan->d_ptr_v;
+    a.X = X;
+    a.Xe_mat = Xe;
+    a.degE = degE;
+    a.W = W;
+    a.degV = degV;
+    a.Y = Y;
+    a.F = F;
+    a.cap = f->cap;
+    a.rows_cap = f->rows_cap;
+    a.mem_cap = f->mem_cap;
+    a.vslot_cap = f->vslot_cap;
+    a.xcd_remap = (plan->opts.flags & HG_PLAN_NO_XCD_REMAP) ? 0 : 1;
+    hipError_t e = hg::launch_fused(a, vec4, s);
+    if (e != hipSuccess) return hip_fail("fused_panel launch", e);
+    return HG_OK;
+  }
   // hop 1: Xe[e] = ((sum_{u in e} X[u]) * degE[e]) * W[e]
   rc = run_hop(plan, 0, F, csrptr_t, colind_t, X, degE, W, Xe,
                reinterpret_cast<float *>(ws + c.part[0]), s);

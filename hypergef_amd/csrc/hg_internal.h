@@ -1,6 +1,8 @@
 // Internal structures of libhgaggr (host side).  Not part of the C ABI.
 #pragma once
 #include <cstdint>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -40,12 +42,48 @@ struct Sched {
   Fixup *d_fixups = nullptr;
 };
 
+// ---- fused (LDS-staged) variant -------------------------------------------
+// One workgroup's share of the non-hub vertices: consecutive rows
+// [row0, row0+nrows) plus the distinct hyperedges they touch ("slots").  Slot k
+// of the panel owns entries [soff[sbase+k], soff[sbase+k+1]) of the panel's
+// slice pmem[pm0 .. pm0+npm): member vertex ids of a recomputed hyperedge, or one
+// entry with bit 31 set = row of the materialised table Xe_mat.
+struct FPanel {
+  int32_t row0, nrows, sbase, nslots, pm0, npm, eid0, pad;
+};
+
+struct FusedSched {
+  int32_t cap = 0;        // slots per panel (LDS tile rows)
+  int32_t rows_cap = 0;   // rows per panel
+  int32_t mem_cap = 0;    // staged member entries per panel
+  int32_t vslot_cap = 0;  // staged (vertex, slot) incidences per panel
+  int32_t t_big = 0;      // hyperedges longer than this are materialised
+  int32_t vdeg_max = 0;   // vertices with more incident hyperedges are "hubs"
+  int32_t n_mat = 0, n_hub = 0;
+  std::vector<FPanel> panels;
+  std::vector<int32_t> soff, pmem, slot_eid;
+  std::vector<uint16_t> vslot;  // aligned with ind_v positions
+  // materialised hyperedges (compact CSR over their members) and hub vertices
+  // (compact CSR over their materialised hyperedges)
+  std::vector<int32_t> mat_ptr, mat_ind, mat_eid, hub_ptr, hub_ind, hub_vid;
+  Sched mat_sched, hub_sched;
+  // device copies
+  FPanel *d_panels = nullptr;
+  int32_t *d_soff = nullptr, *d_pmem = nullptr, *d_slot_eid = nullptr;
+  uint16_t *d_vslot = nullptr;
+  int32_t *d_mat_ptr = nullptr, *d_mat_ind = nullptr, *d_mat_eid = nullptr;
+  int32_t *d_hub_ptr = nullptr, *d_hub_ind = nullptr, *d_hub_vid = nullptr;
+  int64_t pmem_entries = 0;
+};
+
 struct Opts {
   int32_t short_max = 32;
   int32_t split_len = 512;
   int32_t panel_rows = 128;
   int32_t panel_nnz = 1024;
   int32_t flags = 0;
+  int32_t t_big = 8;           // fused: recompute hyperedges of at most this many members
+  int32_t fused_tile_bytes = 16384;  // fused: LDS tile budget -> slot capacity
 };
 
 void set_error(const std::string &msg);
@@ -60,6 +98,9 @@ void transpose_csr(int32_t nrows, int32_t ncols, const int32_t *ptr,
                    const int32_t *ind, std::vector<int32_t> &t_ptr,
                    std::vector<int32_t> &t_ind);
 void build_sched(int32_t nrows, const int32_t *ptr, const Opts &o, Sched &s);
+void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_t,
+                 const int32_t *ptr_v, const int32_t *ind_v, const Opts &o, int32_t cap,
+                 FusedSched &f);
 
 }  // namespace hg
 
@@ -67,9 +108,12 @@ struct hg_plan {
   int32_t N = 0, M = 0;
   int64_t nnz = 0;
   hg::Opts opts;
+  std::vector<int32_t> ptr_t, ind_t;  // H_T CSR (hyperedge -> members), host copy
   std::vector<int32_t> ptr_v, ind_v;  // H CSR (vertex -> hyperedges), host
   int32_t *d_ptr_v = nullptr, *d_ind_v = nullptr;
   hg::Sched sched[2];  // [0]: H_T rows = hyperedges, [1]: H rows = vertices
+  std::map<int32_t, hg::FusedSched> fused;  // keyed by slot capacity (depends on F)
+  std::mutex fused_mu;
   int64_t device_bytes = 0;
   int device = -1;
 };

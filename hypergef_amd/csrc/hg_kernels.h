@@ -16,11 +16,26 @@ struct GatherArgs {
   const float *scaleA;  // per-row factor applied first, or null
   const float *scaleB;  // per-row factor applied second, or null
   float *partial;       // partial-sum slots [nslots, F]
+  const int32_t *scale_map;  // row -> index into scaleA/scaleB, or null (identity)
+  const int32_t *dst_map;    // row -> output row, or null (identity)
   const Panel *panels;
   const Task *tasks;
   int32_t npanels, ntasks, n_task_blocks;
   int32_t F;
   int32_t panel_rows, panel_nnz;  // LDS carve-up
+  int32_t xcd_remap;
+};
+
+struct FusedArgs {
+  const FPanel *panels;
+  int32_t npanels;
+  const int32_t *soff, *pmem, *slot_eid;
+  const uint16_t *vslot;
+  const int32_t *ptr_v;
+  const float *X, *Xe_mat, *degE, *W, *degV;
+  float *Y;
+  int32_t F;
+  int32_t cap, rows_cap, mem_cap, vslot_cap;
   int32_t xcd_remap;
 };
 
@@ -35,6 +50,8 @@ struct PushArgs {
 
 hipError_t launch_gather(const GatherArgs &a, int nfix, const Fixup *fixups, bool vec4,
                          hipStream_t stream);
+hipError_t launch_fused(const FusedArgs &a, bool vec4, hipStream_t stream);
+int fused_tile_row_floats(int F, bool vec4);
 hipError_t launch_push(const PushArgs &a, hipStream_t stream);
 
 }  // namespace hg

@@ -86,9 +86,11 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const GatherArgs a) {
     for (int off = LPR; off < 64; off <<= 1) acc.xor_reduce(off);
     if (g == 0 && col_ok) {
       if (tk.slot < 0) {
-        if (a.scaleA) acc.mul(a.scaleA[tk.row]);
-        if (a.scaleB) acc.mul(a.scaleB[tk.row]);
-        acc.store(a.dst + (int64_t)tk.row * F + col);
+        const int srow = a.scale_map ? a.scale_map[tk.row] : tk.row;
+        const int64_t drow = a.dst_map ? a.dst_map[tk.row] : tk.row;
+        if (a.scaleA) acc.mul(a.scaleA[srow]);
+        if (a.scaleB) acc.mul(a.scaleB[srow]);
+        acc.store(a.dst + drow * F + col);
       } else {
         acc.store(a.partial + (int64_t)tk.slot * F + col);
       }
@@ -108,13 +110,16 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const GatherArgs a) {
   int32_t *sptr = smem;                                         // [panel_rows + 1]
   float *sA = reinterpret_cast<float *>(smem + a.panel_rows + 1);  // [panel_rows]
   float *sB = sA + a.panel_rows;                                // [panel_rows]
-  int32_t *sind = reinterpret_cast<int32_t *>(sB + a.panel_rows);  // [panel_nnz]
+  int32_t *sdst = reinterpret_cast<int32_t *>(sB + a.panel_rows);  // [panel_rows]
+  int32_t *sind = sdst + a.panel_rows;                             // [panel_nnz]
 
   for (int i = tid; i <= pn.nrows; i += 256) sptr[i] = a.ptr[pn.row0 + i] - pn.nnz0;
-  if (a.scaleA)
-    for (int i = tid; i < pn.nrows; i += 256) sA[i] = a.scaleA[pn.row0 + i];
-  if (a.scaleB)
-    for (int i = tid; i < pn.nrows; i += 256) sB[i] = a.scaleB[pn.row0 + i];
+  for (int i = tid; i < pn.nrows; i += 256) {
+    const int srow = a.scale_map ? a.scale_map[pn.row0 + i] : pn.row0 + i;
+    if (a.scaleA) sA[i] = a.scaleA[srow];
+    if (a.scaleB) sB[i] = a.scaleB[srow];
+    if (a.dst_map) sdst[i] = a.dst_map[pn.row0 + i];
+  }
   for (int i = tid; i < pn.nnz_cnt; i += 256) sind[i] = a.ind[pn.nnz0 + i];
   __syncthreads();
 
@@ -129,7 +134,8 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const GatherArgs a) {
       if (a.scaleA) acc.mul(sA[row]);
       if (a.scaleB) acc.mul(sB[row]);
     }
-    if (col_ok) acc.store(a.dst + (int64_t)(pn.row0 + row) * F + col);
+    const int64_t drow = a.dst_map ? sdst[row] : pn.row0 + row;
+    if (col_ok) acc.store(a.dst + drow * F + col);
   };
 
   int pos = sptr[r];
@@ -205,9 +211,124 @@ __global__ __launch_bounds__(256) void fixup_rows_kernel(const GatherArgs a, con
   const int64_t F = a.F;
   V acc = V::zero();
   for (int k = 0; k < fx.count; k++) acc.add(V::load(a.partial + (int64_t)(fx.first + k) * F + col));
-  if (a.scaleA) acc.mul(a.scaleA[fx.row]);
-  if (a.scaleB) acc.mul(a.scaleB[fx.row]);
-  acc.store(a.dst + (int64_t)fx.row * F + col);
+  const int srow = a.scale_map ? a.scale_map[fx.row] : fx.row;
+  const int64_t drow = a.dst_map ? a.dst_map[fx.row] : fx.row;
+  if (a.scaleA) acc.mul(a.scaleA[srow]);
+  if (a.scaleB) acc.mul(a.scaleB[srow]);
+  acc.store(a.dst + drow * F + col);
+}
+
+// Fused V->E->V for one vertex panel, hyperedge sums staged in LDS.
+//  stage : the panel's slot offsets, member entries, (vertex,slot) incidences,
+//          row pointers and scales -> LDS (coalesced loads)
+//  hop 1 : every LPR-lane group walks a contiguous run of slots as one flat entry
+//          stream (U row gathers in flight; an entry with bit 31 set reads the
+//          materialised table instead of X), scales the finished sum by
+//          degE*W and writes it to its row of the LDS tile
+//  hop 2 : every group sums, for each of its vertices, the tile rows of the
+//          vertex's hyperedges in H-CSR order, scales by degV and stores Y.
+// Same arithmetic and order as the two-phase path (and the CPU reference), but
+// the hyperedge feature rows never leave the CU.
+template <int LPR, int VEC, int U>
+__global__ __launch_bounds__(256) void fused_panel_kernel(const FusedArgs a) {
+  constexpr int NG = 256 / LPR;
+  constexpr int TW = LPR * VEC;  // tile row stride in floats
+  using V = Vec<VEC>;
+  extern __shared__ int32_t smem[];
+  const int tid = threadIdx.x;
+  const int gl = tid & (LPR - 1);
+  const int lcol = gl * VEC;
+  const int col = blockIdx.y * TW + lcol;
+  const bool col_ok = col < a.F;
+  const int64_t F = a.F;
+  int b = blockIdx.x;
+  if (a.xcd_remap) {
+    const int x = b & 7, i = b >> 3;
+    const int cpx = a.npanels >> 3, rem = a.npanels & 7;
+    b = x * cpx + (x < rem ? x : rem) + i;
+  }
+  const FPanel pn = a.panels[b];
+
+  float *tile = reinterpret_cast<float *>(smem);            // [cap * TW]
+  int32_t *soff = smem + a.cap * TW;                         // [cap + 1]
+  float *sA = reinterpret_cast<float *>(soff + a.cap + 1);   // [cap]
+  float *sB = sA + a.cap;                                    // [cap]
+  int32_t *spm = reinterpret_cast<int32_t *>(sB + a.cap);    // [mem_cap]
+  int32_t *sptr = spm + a.mem_cap;                           // [rows_cap + 1]
+  float *sdeg = reinterpret_cast<float *>(sptr + a.rows_cap + 1);  // [rows_cap]
+  uint16_t *svs = reinterpret_cast<uint16_t *>(sdeg + a.rows_cap);  // [vslot_cap]
+
+  const int vs0 = a.ptr_v[pn.row0];
+  for (int i = tid; i <= pn.nslots; i += 256) soff[i] = a.soff[pn.sbase + i];
+  for (int i = tid; i < pn.npm; i += 256) spm[i] = a.pmem[pn.pm0 + i];
+  for (int i = tid; i <= pn.nrows; i += 256) sptr[i] = a.ptr_v[pn.row0 + i] - vs0;
+  if (a.degV)
+    for (int i = tid; i < pn.nrows; i += 256) sdeg[i] = a.degV[pn.row0 + i];
+  const int nvs = a.ptr_v[pn.row0 + pn.nrows] - vs0;
+  for (int i = tid; i < nvs; i += 256) svs[i] = a.vslot[vs0 + i];
+  if (a.degE || a.W) {
+    for (int i = tid; i < pn.nslots; i += 256) {
+      const int e = a.slot_eid[pn.eid0 + i];  // -1: materialised row, already scaled
+      sA[i] = (a.degE && e >= 0) ? a.degE[e] : 1.0f;
+      sB[i] = (a.W && e >= 0) ? a.W[e] : 1.0f;
+    }
+  }
+  __syncthreads();
+
+  const int g = tid / LPR;
+  {  // ---- hop 1: slots -> LDS tile
+    const int spg = (pn.nslots + NG - 1) / NG;
+    int k = min(g * spg, pn.nslots);
+    const int ke = min(k + spg, pn.nslots);
+    if (k < ke) {
+      auto flush = [&](int slot, V acc) {
+        if (a.degE) acc.mul(sA[slot]);
+        if (a.W) acc.mul(sB[slot]);
+        acc.store(tile + slot * TW + lcol);
+      };
+      int pos = soff[k];
+      const int stop = soff[ke];
+      int slot_end = soff[k + 1];
+      V acc = V::zero();
+      while (pos < stop) {
+        const int n = min(U, stop - pos);
+        V v[U];
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+          const int ent = spm[pos + min(j, n - 1)];
+          const float *base = ent < 0 ? a.Xe_mat : a.X;
+          const int64_t idx = ent & 0x7fffffff;
+          v[j] = col_ok ? V::load(base + idx * F + col) : V::zero();
+        }
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+          if (j < n) {
+            while (slot_end <= pos + j) {
+              flush(k, acc);
+              acc = V::zero();
+              k++;
+              slot_end = soff[k + 1];
+            }
+            acc.add(v[j]);
+          }
+        }
+        pos += n;
+      }
+      flush(k, acc);  // every slot has at least one entry, so the last one is still open
+    }
+  }
+  __syncthreads();
+  {  // ---- hop 2: vertices <- LDS tile
+    const int rpg = (pn.nrows + NG - 1) / NG;
+    const int r0 = min(g * rpg, pn.nrows), r1 = min(r0 + rpg, pn.nrows);
+    for (int r = r0; r < r1; r++) {
+      V acc = V::zero();
+      const int pb = sptr[r], pe = sptr[r + 1];
+      for (int p = pb; p < pe; p++) acc.add(V::load(tile + (int)svs[p] * TW + lcol));
+      if (a.degV && pe > pb) acc.mul(sdeg[r]);
+      if (col_ok) acc.store(a.Y + (int64_t)(pn.row0 + r) * F + col);
+    }
+  }
 }
 
 // The reference's register-fused scheme on wave64: LPR lanes = LPR feature
@@ -274,7 +395,7 @@ static hipError_t launch_gather_t(const GatherArgs &a, int nfix, const Fixup *fi
   const int col_tiles = (a.F + LPR * VEC - 1) / (LPR * VEC);
   const int nblocks = a.n_task_blocks + a.npanels;
   if (nblocks > 0) {
-    const size_t lds = (size_t)(3 * a.panel_rows + 1 + a.panel_nnz) * sizeof(int32_t);
+    const size_t lds = (size_t)(4 * a.panel_rows + 1 + a.panel_nnz) * sizeof(int32_t);
     const dim3 grid(nblocks, col_tiles), block(256);
     const Tuning &t = tuning();
     if (t.unroll == 8) {
@@ -315,6 +436,42 @@ hipError_t launch_gather(const GatherArgs &a, int nfix, const Fixup *fixups, boo
   }
 #undef HG_CASE
   return hipErrorInvalidValue;
+}
+
+template <int LPR, int VEC>
+static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
+  if (a.npanels == 0) return hipSuccess;
+  constexpr int TW = LPR * VEC;
+  const int col_tiles = (a.F + TW - 1) / TW;
+  const size_t lds = (size_t)a.cap * TW * 4 + (size_t)(a.cap + 1 + 2 * a.cap + a.mem_cap + a.rows_cap + 1 + a.rows_cap) * 4 +
+                     (size_t)a.vslot_cap * 2 + 16;
+  hipLaunchKernelGGL((fused_panel_kernel<LPR, VEC, 4>), dim3(a.npanels, col_tiles), dim3(256), lds, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_fused(const FusedArgs &a, bool vec4, hipStream_t stream) {
+  const int lanes = vec4 ? a.F / 4 : a.F;
+  const int lpr = std::min(64, next_pow2(std::max(lanes, 1)));
+#define HG_CASE(L) \
+  case L:          \
+    return vec4 ? launch_fused_t<L, 4>(a, stream) : launch_fused_t<L, 1>(a, stream);
+  switch (lpr) {
+    HG_CASE(1)
+    HG_CASE(2)
+    HG_CASE(4)
+    HG_CASE(8)
+    HG_CASE(16)
+    HG_CASE(32)
+    HG_CASE(64)
+  }
+#undef HG_CASE
+  return hipErrorInvalidValue;
+}
+
+// floats per LDS tile row for feature width F (what launch_fused will use)
+int fused_tile_row_floats(int F, bool vec4) {
+  const int lanes = vec4 ? F / 4 : F;
+  return std::min(64, next_pow2(std::max(lanes, 1))) * (vec4 ? 4 : 1);
 }
 
 hipError_t launch_push(const PushArgs &a, hipStream_t stream) {

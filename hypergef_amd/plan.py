@@ -24,13 +24,14 @@ def _stream_handle(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def make_opts(short_max=0, split_len=0, panel_rows=0, panel_nnz=0, xcd_remap=True, host_only=False):
+def make_opts(short_max=0, split_len=0, panel_rows=0, panel_nnz=0, xcd_remap=True, host_only=False,
+              t_big=0, fused_tile_bytes=0):
     flags = 0
     if host_only:
         flags |= _lib.HG_PLAN_HOST_ONLY
     if not xcd_remap:
         flags |= _lib.HG_PLAN_NO_XCD_REMAP
-    return _lib.PlanOpts(short_max, split_len, panel_rows, panel_nnz, flags)
+    return _lib.PlanOpts(short_max, split_len, panel_rows, panel_nnz, flags, t_big, fused_tile_bytes)
 
 
 class Plan:
@@ -99,6 +100,12 @@ class Plan:
         _lib.check(_lib.lib().hg_plan_get_schedule(
             self._h, hop, *(out[k].ctypes.data_as(ctypes.c_void_p) for k in ("panels", "tasks", "fixups"))))
         return out
+
+    def prepare(self, F):
+        """Build the feature-width dependent (fused) schedule now; returns its shape."""
+        info = _lib.FusedInfo()
+        _lib.check(_lib.lib().hg_plan_prepare(self._h, F, ctypes.byref(info)))
+        return info.as_dict()
 
     def workspace_bytes(self, F):
         return int(_lib.lib().hg_plan_workspace_bytes(self._h, F))

@@ -58,7 +58,13 @@ typedef enum hg_variant {
   HG_VARIANT_PULL = 1,
   /* The reference's scheme (HGNNAggr_forward_kernel, hgnnaggr_cuda.cu:14-47):
    * hyperedge partial sum kept in registers, scattered with fp32 atomics. */
-  HG_VARIANT_PUSH_ATOMIC = 2
+  HG_VARIANT_PUSH_ATOMIC = 2,
+  /* Fused pull: vertex panels whose incident hyperedge sums are recomputed in
+   * the workgroup and staged in LDS, so the M x F hyperedge feature matrix
+   * never round-trips through HBM.  Hyperedges longer than t_big and the
+   * hyperedges of hub vertices are materialised by a pre-pass instead.
+   * Same arithmetic order as HG_VARIANT_PULL. */
+  HG_VARIANT_FUSED = 3
 } hg_variant;
 
 typedef struct hg_plan_opts {
@@ -67,6 +73,8 @@ typedef struct hg_plan_opts {
   int32_t panel_rows; /* rows per row-panel workgroup (default 128)                   */
   int32_t panel_nnz;  /* index entries staged in LDS per panel (default 1024)         */
   int32_t flags;      /* HG_PLAN_* bits                                              */
+  int32_t t_big;      /* fused: recompute hyperedges of at most this many members (8)  */
+  int32_t fused_tile_bytes; /* fused: LDS tile budget per workgroup (16384)              */
 } hg_plan_opts;
 
 #define HG_PLAN_HOST_ONLY 1 /* build the schedule on the host, upload nothing (tests) */
@@ -84,6 +92,17 @@ typedef struct hg_plan_info {
   int32_t max_len[2];  /* longest row of each CSR                      */
   int64_t device_bytes; /* device memory held by the plan              */
 } hg_plan_info;
+
+/* Shape of the F-dependent fused schedule (hg_plan_prepare). */
+typedef struct hg_fused_info {
+  int32_t cap;      /* hyperedge slots (LDS tile rows) per vertex panel */
+  int32_t t_big, vdeg_max;
+  int32_t panels;
+  int32_t n_mat;    /* materialised hyperedges */
+  int32_t n_hub;    /* hub vertices (handled by plain row gathers) */
+  int64_t slots;    /* sum over panels of distinct hyperedges touched */
+  int64_t member_entries; /* row gathers of one fused aggregation (panels only) */
+} hg_fused_info;
 
 HG_API int hg_version(void);
 HG_API const char *hg_last_error(void);
@@ -127,6 +146,11 @@ HG_API int hg_plan_get_vertex_csr(const hg_plan *plan, int32_t *ptr_v_host,
 /* Device pointers of the derived H CSR (valid for the plan's lifetime). */
 HG_API int hg_plan_get_vertex_csr_device(const hg_plan *plan, const int32_t **ptr_v_dev,
                                   const int32_t **ind_v_dev);
+/* Build (and upload) the part of the plan that depends on the feature width --
+ * the fused variant's vertex panels -- ahead of time.  hg_aggr_fused_f32 does
+ * this itself on first use of a width, but that first call allocates device
+ * memory and so cannot be captured into a hipGraph.  info may be NULL. */
+HG_API int hg_plan_prepare(const hg_plan *plan, int32_t F, hg_fused_info *info);
 /* Host copy of one hop's schedule as int32 quadruples (tests, tools): panels
  * {row0, nrows, nnz0, nnz_cnt}, tasks {row, beg, end, slot}, fixups {row,
  * first_slot, count, 0}; sizes from hg_plan_get_info.  Pointers may be NULL. */

@@ -71,6 +71,10 @@ def test_unweighted_matches_reference_host_path(hg, oracle, shape, F):
     _assert_close(Y, ref)
     if plan.info["max_len"][0] <= plan.info["short_max"] and plan.info["max_len"][1] <= plan.info["short_max"]:
         assert np.array_equal(Y, ref), "short rows must reproduce the CPU order bit for bit"
+    Yf = plan.aggregate(ptr, ind, _dev(X), variant="fused").cpu().numpy()
+    _assert_close(Yf, ref)
+    if plan.info["max_len"][0] <= 8 and plan.info["max_len"][1] <= 16:
+        assert np.array_equal(Yf, ref), "fused panels keep the CPU order too"
     Yp = plan.aggregate(ptr, ind, _dev(X), variant="push_atomic").cpu().numpy()
     _assert_close(Yp, ref)
 
@@ -85,14 +89,14 @@ def test_hgnnaggr_matches_hgnn_check(hg, oracle, shape, F):
     degE = np.where(np.isinf(degE), 0, degE).astype(np.float32) if shape == "powerlaw" else degE
     ref = oracle.hgnn_check(inc.N, inc.M, F, H_ptr, H_ind, inc.csrptr, inc.colind, X, degE, degV, W)
     hyperg = hg.HyperGraph.from_incidence(inc, DEV, ngs=40)
-    for variant in ("pull", "push_atomic", "push_groups"):
+    for variant in ("pull", "fused", "push_atomic", "push_groups"):
         hg.ops.set_variant(variant)
         try:
             Y = hg.HGNNAggr(hyperg, _dev(X), _dev(degE), _dev(degV), _dev(W.reshape(-1, 1)))
         finally:
             hg.ops.set_variant("auto")
         assert Y.shape == (inc.N, F) and Y.device.type == "cuda"
-        if variant == "pull" or shape not in ("dense", "powerlaw"):
+        if variant in ("pull", "fused") or shape not in ("dense", "powerlaw"):
             _assert_close(Y, ref)
         else:  # atomics on hub rows: thousands of terms in arbitrary order
             np.testing.assert_allclose(Y.cpu().numpy(), ref, rtol=2e-4, atol=2e-5)
@@ -146,9 +150,11 @@ def test_split_rows_and_edge_cases(hg, oracle):
                      make_opts(short_max=1, split_len=1, panel_rows=1, panel_nnz=1),
                      make_opts(short_max=4, split_len=7, panel_rows=3, panel_nnz=9, xcd_remap=False)):
             plan = Plan.from_tensors(inc.N, ptr, ind, opts)
-            Y = plan.aggregate(ptr, ind, _dev(X), _dev(degE.ravel()), _dev(degV.ravel()), _dev(W))
-            assert torch.isfinite(Y).all()
-            _assert_close(Y, ref)
+            for variant in ("pull", "fused"):
+                Y = plan.aggregate(ptr, ind, _dev(X), _dev(degE.ravel()), _dev(degV.ravel()), _dev(W),
+                                   variant=variant)
+                assert torch.isfinite(Y).all()
+                _assert_close(Y, ref)
 
 
 def test_degenerate_graphs(hg):
@@ -157,8 +163,9 @@ def test_degenerate_graphs(hg):
     ptr = torch.zeros(1, dtype=torch.int32, device=DEV)
     ind = torch.zeros(0, dtype=torch.int32, device=DEV)
     plan = Plan.from_tensors(5, ptr, ind)
-    Y = plan.aggregate(ptr, ind, torch.ones(5, 8, device=DEV))
-    assert Y.shape == (5, 8) and (Y == 0).all()
+    for variant in ("pull", "fused"):
+        Y = plan.aggregate(ptr, ind, torch.ones(5, 8, device=DEV), variant=variant)
+        assert Y.shape == (5, 8) and (Y == 0).all()
     # one hyperedge holding every vertex
     n = 1000
     ptr = torch.tensor([0, n], dtype=torch.int32, device=DEV)
@@ -167,6 +174,7 @@ def test_degenerate_graphs(hg):
     X = torch.ones(n, 4, device=DEV)
     Y = plan.aggregate(ptr, ind, X)
     assert (Y == n).all()
+    assert (plan.aggregate(ptr, ind, X, variant="fused") == n).all()
 
 
 def test_reference_schedule_drives_push_kernel(hg, oracle):
@@ -273,3 +281,22 @@ def test_full_size_properties(hg, oracle, F, K):
     # linearity in X (exact for a power-of-two factor)
     Y2 = plan.aggregate(ptr, ind, X * 4.0).view(K, base.N, F)
     assert torch.equal(Y2, Y * 4.0)
+
+
+@pytest.mark.parametrize("shape", ["cora", "pubmed", "dense", "powerlaw"])
+@pytest.mark.parametrize("opts", [dict(), dict(t_big=2, fused_tile_bytes=2048), dict(t_big=64, fused_tile_bytes=65536)])
+def test_fused_variant_schedules(hg, oracle, shape, opts):
+    """Fused panels under different slot capacities / materialisation thresholds:
+    recomputed slots, materialised slots and hub vertices all in play."""
+    from hypergef_amd.plan import Plan, make_opts
+    inc = _make(shape)
+    ptr, ind = _dev(inc.csrptr), _dev(inc.colind)
+    plan = Plan.from_tensors(inc.N, ptr, ind, make_opts(**opts))
+    for F in (32, 6, 128):
+        X, degE, degV, W, H_ptr, H_ind = _inputs(inc, F, oracle, seed=F, normal=True)
+        degE = np.where(np.isinf(degE), 0, degE).astype(np.float32)
+        ref = oracle.hgnn_check(inc.N, inc.M, F, H_ptr, H_ind, inc.csrptr, inc.colind, X, degE, degV, W)
+        info = plan.prepare(F)
+        assert info["panels"] > 0 or info["n_hub"] == inc.N
+        Y = plan.aggregate(ptr, ind, _dev(X), _dev(degE.ravel()), _dev(degV.ravel()), _dev(W), variant="fused")
+        _assert_close(Y, ref)
