@@ -30,9 +30,9 @@ _STATE = {"variant": "auto", "backward": "reference"}
 
 
 def set_variant(name):
-    """'auto' | 'pull' | 'push_atomic' (plan-free hyperedge tasks) | 'push_groups'
+    """'auto' | 'pull' | 'fused' | 'push_atomic' (one task per hyperedge) | 'push_groups'
     (the caller's group_* tensors drive the reference-style kernel)."""
-    if name not in ("auto", "pull", "push_atomic", "push_groups"):
+    if name not in ("auto", "pull", "fused", "push_atomic", "push_groups"):
         raise ValueError("unknown variant %r" % (name,))
     _STATE["variant"] = name
 
