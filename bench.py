@@ -45,7 +45,9 @@ def parse():
     p.add_argument("--shape", default="cora", choices=["cora", "citeseer", "pubmed", "powerlaw"])
     p.add_argument("--replicas", type=int, default=1024, help="hypergraphs per GPU in the batch")
     p.add_argument("--feat", type=int, default=32)
-    p.add_argument("--variant", default="auto", choices=["auto", "pull", "push_atomic"])
+    p.add_argument("--variant", default="auto", choices=["auto", "pull", "fused", "push_atomic"])
+    p.add_argument("--t-big", type=int, default=0)
+    p.add_argument("--tile-bytes", type=int, default=0)
     p.add_argument("--weighted", action="store_true", help="hgnnaggr (degE, degV, W) instead of H H^T X")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true", help="skip single-graph / all-reduce extras")
@@ -162,7 +164,8 @@ def main():
     ind = torch.from_numpy(inc.colind).to(dev)
     X = torch.from_numpy(X_host).to(dev)
     opts = planmod.make_opts(short_max=args.short_max, panel_rows=args.panel_rows,
-                             panel_nnz=args.panel_nnz, xcd_remap=not args.no_xcd_remap)
+                             panel_nnz=args.panel_nnz, xcd_remap=not args.no_xcd_remap,
+                             t_big=args.t_big, fused_tile_bytes=args.tile_bytes)
     t0 = time.perf_counter()
     plan = planmod.Plan.from_tensors(inc.N, ptr, ind, opts)
     plan_s = time.perf_counter() - t0
@@ -189,7 +192,7 @@ def main():
 
     total_nnz = inc.nnz * world
     value = total_nnz * args.steps / wall
-    launches = 2 if args.variant != "push_atomic" else 1
+    launches = 2 if args.variant in ("auto", "pull") else 1
     balg = b_alg(inc.N, inc.M, inc.nnz, F, n_w)
     kern_avg_s = dev_s / (args.steps * launches)
     achieved = balg / launches / kern_avg_s / 1e9
