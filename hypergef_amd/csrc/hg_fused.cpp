@@ -74,6 +74,8 @@ void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_
   auto close_panel = [&](int32_t end_row) {
     cur.nrows = end_row - cur.row0;
     if (cur.nrows > 0) {
+      cur.vs0 = ptr_v[cur.row0];
+      cur.nvs = ptr_v[end_row] - ptr_v[cur.row0];
       cur.npm = (int32_t)f.pmem.size() - cur.pm0;
       f.panels.push_back(cur);
     } else {

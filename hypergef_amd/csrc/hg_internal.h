@@ -49,7 +49,7 @@ struct Sched {
 // slice pmem[pm0 .. pm0+npm): member vertex ids of a recomputed hyperedge, or one
 // entry with bit 31 set = row of the materialised table Xe_mat.
 struct FPanel {
-  int32_t row0, nrows, sbase, nslots, pm0, npm, eid0, pad;
+  int32_t row0, nrows, sbase, nslots, pm0, npm, eid0, vs0, nvs, pad0, pad1, pad2;
 };
 
 struct FusedSched {

@@ -229,9 +229,9 @@ __global__ __launch_bounds__(256) void fixup_rows_kernel(const GatherArgs a, con
 //          vertex's hyperedges in H-CSR order, scales by degV and stores Y.
 // Same arithmetic and order as the two-phase path (and the CPU reference), but
 // the hyperedge feature rows never leave the CU.
-template <int LPR, int VEC, int U>
-__global__ __launch_bounds__(256) void fused_panel_kernel(const FusedArgs a) {
-  constexpr int NG = 256 / LPR;
+template <int LPR, int VEC, int U, int BS>
+__global__ __launch_bounds__(BS) void fused_panel_kernel(const FusedArgs a) {
+  constexpr int NG = BS / LPR;
   constexpr int TW = LPR * VEC;  // tile row stride in floats
   using V = Vec<VEC>;
   extern __shared__ int32_t smem[];
@@ -258,16 +258,16 @@ __global__ __launch_bounds__(256) void fused_panel_kernel(const FusedArgs a) {
   float *sdeg = reinterpret_cast<float *>(sptr + a.rows_cap + 1);  // [rows_cap]
   uint16_t *svs = reinterpret_cast<uint16_t *>(sdeg + a.rows_cap);  // [vslot_cap]
 
-  const int vs0 = a.ptr_v[pn.row0];
-  for (int i = tid; i <= pn.nslots; i += 256) soff[i] = a.soff[pn.sbase + i];
-  for (int i = tid; i < pn.npm; i += 256) spm[i] = a.pmem[pn.pm0 + i];
-  for (int i = tid; i <= pn.nrows; i += 256) sptr[i] = a.ptr_v[pn.row0 + i] - vs0;
+  const int vs0 = pn.vs0;
+  for (int i = tid; i <= pn.nslots; i += BS) soff[i] = a.soff[pn.sbase + i];
+  for (int i = tid; i < pn.npm; i += BS) spm[i] = a.pmem[pn.pm0 + i];
+  for (int i = tid; i <= pn.nrows; i += BS) sptr[i] = a.ptr_v[pn.row0 + i] - vs0;
   if (a.degV)
-    for (int i = tid; i < pn.nrows; i += 256) sdeg[i] = a.degV[pn.row0 + i];
-  const int nvs = a.ptr_v[pn.row0 + pn.nrows] - vs0;
-  for (int i = tid; i < nvs; i += 256) svs[i] = a.vslot[vs0 + i];
+    for (int i = tid; i < pn.nrows; i += BS) sdeg[i] = a.degV[pn.row0 + i];
+  const int nvs = pn.nvs;
+  for (int i = tid; i < nvs; i += BS) svs[i] = a.vslot[vs0 + i];
   if (a.degE || a.W) {
-    for (int i = tid; i < pn.nslots; i += 256) {
+    for (int i = tid; i < pn.nslots; i += BS) {
       const int e = a.slot_eid[pn.eid0 + i];  // -1: materialised row, already scaled
       sA[i] = (a.degE && e >= 0) ? a.degE[e] : 1.0f;
       sB[i] = (a.W && e >= 0) ? a.W[e] : 1.0f;
@@ -377,6 +377,8 @@ static inline int next_pow2(int x) {
 struct Tuning {
   int unroll = 4;
   int pipe = 0;
+  int fused_bs = 256;
+  int fused_u = 4;
 };
 // Experiment knobs (HG_UNROLL = 4|8, HG_PIPE = 0|1), read once.
 static const Tuning &tuning() {
@@ -384,6 +386,8 @@ static const Tuning &tuning() {
     Tuning x;
     if (const char *e = getenv("HG_UNROLL")) x.unroll = atoi(e) == 8 ? 8 : 4;
     if (const char *e = getenv("HG_PIPE")) x.pipe = atoi(e) != 0;
+    if (const char *e = getenv("HG_FUSED_BS")) x.fused_bs = atoi(e);
+    if (const char *e = getenv("HG_FUSED_U")) x.fused_u = atoi(e);
     return x;
   }();
   return t;
@@ -445,7 +449,18 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
   const int col_tiles = (a.F + TW - 1) / TW;
   const size_t lds = (size_t)a.cap * TW * 4 + (size_t)(a.cap + 1 + 2 * a.cap + a.mem_cap + a.rows_cap + 1 + a.rows_cap) * 4 +
                      (size_t)a.vslot_cap * 2 + 16;
-  hipLaunchKernelGGL((fused_panel_kernel<LPR, VEC, 4>), dim3(a.npanels, col_tiles), dim3(256), lds, stream, a);
+  const dim3 grid(a.npanels, col_tiles);
+  const Tuning &t = tuning();
+#define HG_FUSED(UU, BB) \
+  hipLaunchKernelGGL((fused_panel_kernel<LPR, VEC, UU, BB>), grid, dim3(BB), lds, stream, a)
+  if (t.fused_bs == 512) {
+    if (t.fused_u == 8) HG_FUSED(8, 512); else HG_FUSED(4, 512);
+  } else if (t.fused_bs == 1024) {
+    if (t.fused_u == 8) HG_FUSED(8, 1024); else HG_FUSED(4, 1024);
+  } else {
+    if (t.fused_u == 8) HG_FUSED(8, 256); else HG_FUSED(4, 256);
+  }
+#undef HG_FUSED
   return hipGetLastError();
 }
 
