@@ -94,7 +94,9 @@ int fused_upload(hg::FusedSched &f, int64_t &bytes) {
   UP(soff, d_soff);
   UP(pmem, d_pmem);
   UP(slot_eid, d_slot_eid);
-  UP(vslot, d_vslot);
+  UP(prow, d_prow);
+  UP(pend, d_pend);
+  UP(pvs, d_pvs);
   UP(mat_ptr, d_mat_ptr);
   UP(mat_ind, d_mat_ind);
   UP(mat_eid, d_mat_eid);
@@ -107,7 +109,7 @@ int fused_upload(hg::FusedSched &f, int64_t &bytes) {
 }
 
 void fused_free(hg::FusedSched &f) {
-  void *ptrs[] = {f.d_panels, f.d_soff, f.d_pmem, f.d_slot_eid, f.d_vslot, f.d_mat_ptr,
+  void *ptrs[] = {f.d_panels, f.d_soff, f.d_pmem, f.d_slot_eid, f.d_prow, f.d_pend, f.d_pvs, f.d_mat_ptr,
                   f.d_mat_ind, f.d_mat_eid, f.d_hub_ptr, f.d_hub_ind, f.d_hub_vid};
   for (void *q : ptrs)
     if (q) (void)hipFree(q);
@@ -141,9 +143,8 @@ int get_fused(const hg_plan *cp, int32_t F, bool vec4, const hg::FusedSched **ou
     }
     // the kernel's LDS carve-up trusts these bounds: check them before anything can launch
     for (const hg::FPanel &pn : f.panels) {
-      const int32_t nvs = p->ptr_v[pn.row0 + pn.nrows] - p->ptr_v[pn.row0];
       if (pn.nrows <= 0 || pn.nrows > f.rows_cap || pn.nslots > f.cap || pn.npm > f.mem_cap ||
-          nvs > f.vslot_cap || pn.row0 < 0 || pn.row0 + pn.nrows > p->N) {
+          pn.nvs > f.vslot_cap || pn.r0 < 0 || (size_t)(pn.r0 + pn.nrows) > f.prow.size()) {
         hg::set_error("fused schedule: internal error, panel exceeds its LDS budget");
         return HG_ERR_INVALID;
       }
@@ -520,8 +521,9 @@ int hg_aggr_fused_f32(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
     a.soff = f->d_soff;
     a.pmem = f->d_pmem;
     a.slot_eid = f->d_slot_eid;
-    a.vslot = f->d_vslot;
-    a.ptr_v = plan->d_ptr_v;
+    a.prow = f->d_prow;
+    a.pend = f->d_pend;
+    a.pvs = f->d_pvs;
     a.X = X;
     a.Xe_mat = Xe;
     a.degE = degE;

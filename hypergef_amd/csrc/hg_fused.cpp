@@ -56,65 +56,104 @@ void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_
   build_sched(f.n_mat, f.mat_ptr.data(), o, f.mat_sched);
   build_sched(f.n_hub, f.hub_ptr.data(), o, f.hub_sched);
 
-  // fused panels over the non-hub vertices
-  f.vslot.assign((size_t)nnz, 0);
+  // Row order: depth-first post-order over the bipartite vertex/hyperedge graph,
+  // so that a panel (a run of this order) holds vertices that share hyperedges:
+  // each hyperedge a panel touches costs that panel one slot and one pass over
+  // its members, whatever the number of the panel's vertices that use it.
+  std::vector<int32_t> order;
+  order.reserve((size_t)N);
+  {
+    std::vector<uint8_t> vis((size_t)N, 0), seen((size_t)M, 0);
+    struct Frame {
+      int32_t v, ep, up;  // vertex, position in its hyperedge list, position in that hyperedge
+    };
+    std::vector<Frame> st;
+    for (int32_t root = 0; root < N; root++) {
+      if (vis[root] || is_hub[root]) continue;
+      vis[root] = 1;
+      st.push_back(Frame{root, ptr_v[root], -1});
+      while (!st.empty()) {
+        Frame &fr = st.back();
+        bool descended = false;
+        while (fr.ep < ptr_v[fr.v + 1] && !descended) {
+          const int32_t e = ind_v[fr.ep];
+          if (fr.up < 0) {  // first look at this hyperedge from this vertex
+            if (seen[e] || is_mat[e]) {
+              fr.ep++;
+              continue;
+            }
+            seen[e] = 1;
+            fr.up = ptr_t[e];
+          }
+          while (fr.up < ptr_t[e + 1]) {
+            const int32_t u = ind_t[fr.up++];
+            if (!vis[u] && !is_hub[u]) {
+              vis[u] = 1;
+              st.push_back(Frame{u, ptr_v[u], -1});  // invalidates fr
+              descended = true;
+              break;
+            }
+          }
+          if (!descended) {
+            fr.ep++;
+            fr.up = -1;
+          }
+        }
+        if (!descended) {
+          order.push_back(st.back().v);
+          st.pop_back();
+        }
+      }
+    }
+  }
+
+  // fused panels over that order
   std::vector<int32_t> stamp((size_t)M, -1), slot_of((size_t)M, 0);
-  int32_t start = 0;
   FPanel cur{};
-  int32_t vs_cnt = 0;
-  auto open_panel = [&](int32_t row0) {
+  auto open_panel = [&]() {
     cur = FPanel{};
-    cur.row0 = row0;
+    cur.r0 = (int32_t)f.prow.size();
     cur.sbase = (int32_t)f.soff.size();
     cur.pm0 = (int32_t)f.pmem.size();
     cur.eid0 = (int32_t)f.slot_eid.size();
-    vs_cnt = 0;
+    cur.v0 = (int32_t)f.pvs.size();
     f.soff.push_back(0);
   };
-  auto close_panel = [&](int32_t end_row) {
-    cur.nrows = end_row - cur.row0;
+  auto close_panel = [&]() {
+    cur.nrows = (int32_t)f.prow.size() - cur.r0;
     if (cur.nrows > 0) {
-      cur.vs0 = ptr_v[cur.row0];
-      cur.nvs = ptr_v[end_row] - ptr_v[cur.row0];
       cur.npm = (int32_t)f.pmem.size() - cur.pm0;
+      cur.nvs = (int32_t)f.pvs.size() - cur.v0;
       f.panels.push_back(cur);
     } else {
       f.soff.pop_back();  // the opening 0 of an empty panel
     }
   };
-  open_panel(0);
-  start = 0;
-  for (int32_t v = 0; v < N; v++) {
-    if (is_hub[v]) {
-      close_panel(v);
-      open_panel(v + 1);
-      start = v + 1;
-      continue;
-    }
-    const int32_t pid = (int32_t)f.panels.size();
-    // what would this row add?
+  open_panel();
+  for (const int32_t v : order) {
+    int32_t pid = (int32_t)f.panels.size();
     int32_t new_slots = 0, new_mem = 0;
     for (int32_t p = ptr_v[v]; p < ptr_v[v + 1]; p++) {
       const int32_t e = ind_v[p];
-      if (stamp[e] != pid) {
-        // a hyperedge listed twice for v (duplicate incidence) is counted twice here; harmless
+      if (stamp[e] != pid) {  // a duplicate incidence is counted twice here; harmless
         new_slots++;
         new_mem += is_mat[e] ? 1 : (ptr_t[e + 1] - ptr_t[e]);
       }
     }
     const int32_t deg = ptr_v[v + 1] - ptr_v[v];
+    const int32_t rows = (int32_t)f.prow.size() - cur.r0;
     const int32_t cur_mem = (int32_t)f.pmem.size() - cur.pm0;
-    if (v > start && (v - start == f.rows_cap || cur.nslots + new_slots > f.cap ||
-                      cur_mem + new_mem > f.mem_cap || vs_cnt + deg > f.vslot_cap)) {
-      close_panel(v);
-      open_panel(v);
-      start = v;
+    const int32_t cur_vs = (int32_t)f.pvs.size() - cur.v0;
+    if (rows > 0 && (rows == f.rows_cap || cur.nslots + new_slots > f.cap ||
+                     cur_mem + new_mem > f.mem_cap || cur_vs + deg > f.vslot_cap)) {
+      close_panel();
+      open_panel();
+      pid = (int32_t)f.panels.size();
     }
-    const int32_t pid2 = (int32_t)f.panels.size();
     for (int32_t p = ptr_v[v]; p < ptr_v[v + 1]; p++) {
       const int32_t e = ind_v[p];
-      if (stamp[e] != pid2) {
-        stamp[e] = pid2;
+      if (stamp[e] != pid) {
+        stamp[e] = pid;
         slot_of[e] = cur.nslots++;
         if (is_mat[e]) {
           f.pmem.push_back((int32_t)(0x80000000u | (uint32_t)mat_id[e]));
@@ -125,11 +164,12 @@ void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_
         }
         f.soff.push_back((int32_t)f.pmem.size() - cur.pm0);
       }
-      f.vslot[(size_t)p] = (uint16_t)slot_of[e];
+      f.pvs.push_back((uint16_t)slot_of[e]);
     }
-    vs_cnt += deg;
+    f.prow.push_back(v);
+    f.pend.push_back((int32_t)f.pvs.size() - cur.v0);
   }
-  close_panel(N);
+  close_panel();
   f.pmem_entries = (int64_t)f.pmem.size();
 }
 

@@ -43,13 +43,15 @@ struct Sched {
 };
 
 // ---- fused (LDS-staged) variant -------------------------------------------
-// One workgroup's share of the non-hub vertices: consecutive rows
-// [row0, row0+nrows) plus the distinct hyperedges they touch ("slots").  Slot k
+// One workgroup's share of the non-hub vertices: the rows prow[r0 .. r0+nrows)
+// (any vertex set; the plan clusters vertices that share hyperedges), their
+// incidences as local slot ids pvs[v0 .. v0+nvs) with per-row end offsets
+// pend[r0+i], plus the distinct hyperedges they touch ("slots").  Slot k
 // of the panel owns entries [soff[sbase+k], soff[sbase+k+1]) of the panel's
 // slice pmem[pm0 .. pm0+npm): member vertex ids of a recomputed hyperedge, or one
 // entry with bit 31 set = row of the materialised table Xe_mat.
 struct FPanel {
-  int32_t row0, nrows, sbase, nslots, pm0, npm, eid0, vs0, nvs, pad0, pad1, pad2;
+  int32_t r0, nrows, sbase, nslots, pm0, npm, eid0, v0, nvs, pad0, pad1, pad2;
 };
 
 struct FusedSched {
@@ -62,7 +64,8 @@ struct FusedSched {
   int32_t n_mat = 0, n_hub = 0;
   std::vector<FPanel> panels;
   std::vector<int32_t> soff, pmem, slot_eid;
-  std::vector<uint16_t> vslot;  // aligned with ind_v positions
+  std::vector<int32_t> prow, pend;  // panel rows (vertex ids) and their local end offsets
+  std::vector<uint16_t> pvs;        // panel-ordered incidences: local slot ids
   // materialised hyperedges (compact CSR over their members) and hub vertices
   // (compact CSR over their materialised hyperedges)
   std::vector<int32_t> mat_ptr, mat_ind, mat_eid, hub_ptr, hub_ind, hub_vid;
@@ -70,7 +73,8 @@ struct FusedSched {
   // device copies
   FPanel *d_panels = nullptr;
   int32_t *d_soff = nullptr, *d_pmem = nullptr, *d_slot_eid = nullptr;
-  uint16_t *d_vslot = nullptr;
+  int32_t *d_prow = nullptr, *d_pend = nullptr;
+  uint16_t *d_pvs = nullptr;
   int32_t *d_mat_ptr = nullptr, *d_mat_ind = nullptr, *d_mat_eid = nullptr;
   int32_t *d_hub_ptr = nullptr, *d_hub_ind = nullptr, *d_hub_vid = nullptr;
   int64_t pmem_entries = 0;

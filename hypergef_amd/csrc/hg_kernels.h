@@ -30,8 +30,8 @@ struct FusedArgs {
   const FPanel *panels;
   int32_t npanels;
   const int32_t *soff, *pmem, *slot_eid;
-  const uint16_t *vslot;
-  const int32_t *ptr_v;
+  const int32_t *prow, *pend;
+  const uint16_t *pvs;
   const float *X, *Xe_mat, *degE, *W, *degV;
   float *Y;
   int32_t F;

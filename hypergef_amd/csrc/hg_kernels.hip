@@ -256,16 +256,19 @@ __global__ __launch_bounds__(BS) void fused_panel_kernel(const FusedArgs a) {
   int32_t *spm = reinterpret_cast<int32_t *>(sB + a.cap);    // [mem_cap]
   int32_t *sptr = spm + a.mem_cap;                           // [rows_cap + 1]
   float *sdeg = reinterpret_cast<float *>(sptr + a.rows_cap + 1);  // [rows_cap]
-  uint16_t *svs = reinterpret_cast<uint16_t *>(sdeg + a.rows_cap);  // [vslot_cap]
+  int32_t *srow = reinterpret_cast<int32_t *>(sdeg + a.rows_cap);  // [rows_cap]
+  uint16_t *svs = reinterpret_cast<uint16_t *>(srow + a.rows_cap);  // [vslot_cap]
 
-  const int vs0 = pn.vs0;
   for (int i = tid; i <= pn.nslots; i += BS) soff[i] = a.soff[pn.sbase + i];
   for (int i = tid; i < pn.npm; i += BS) spm[i] = a.pmem[pn.pm0 + i];
-  for (int i = tid; i <= pn.nrows; i += BS) sptr[i] = a.ptr_v[pn.row0 + i] - vs0;
-  if (a.degV)
-    for (int i = tid; i < pn.nrows; i += BS) sdeg[i] = a.degV[pn.row0 + i];
-  const int nvs = pn.nvs;
-  for (int i = tid; i < nvs; i += BS) svs[i] = a.vslot[vs0 + i];
+  if (tid == 0) sptr[0] = 0;
+  for (int i = tid; i < pn.nrows; i += BS) {
+    sptr[i + 1] = a.pend[pn.r0 + i];
+    const int v = a.prow[pn.r0 + i];
+    srow[i] = v;
+    if (a.degV) sdeg[i] = a.degV[v];
+  }
+  for (int i = tid; i < pn.nvs; i += BS) svs[i] = a.pvs[pn.v0 + i];
   if (a.degE || a.W) {
     for (int i = tid; i < pn.nslots; i += BS) {
       const int e = a.slot_eid[pn.eid0 + i];  // -1: materialised row, already scaled
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(BS) void fused_panel_kernel(const FusedArgs a) {
       const int pb = sptr[r], pe = sptr[r + 1];
       for (int p = pb; p < pe; p++) acc.add(V::load(tile + (int)svs[p] * TW + lcol));
       if (a.degV && pe > pb) acc.mul(sdeg[r]);
-      if (col_ok) acc.store(a.Y + (int64_t)(pn.row0 + r) * F + col);
+      if (col_ok) acc.store(a.Y + (int64_t)srow[r] * F + col);
     }
   }
 }
@@ -447,7 +450,7 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
   if (a.npanels == 0) return hipSuccess;
   constexpr int TW = LPR * VEC;
   const int col_tiles = (a.F + TW - 1) / TW;
-  const size_t lds = (size_t)a.cap * TW * 4 + (size_t)(a.cap + 1 + 2 * a.cap + a.mem_cap + a.rows_cap + 1 + a.rows_cap) * 4 +
+  const size_t lds = (size_t)a.cap * TW * 4 + (size_t)(a.cap + 1 + 2 * a.cap + a.mem_cap + a.rows_cap + 1 + 2 * a.rows_cap) * 4 +
                      (size_t)a.vslot_cap * 2 + 16;
   const dim3 grid(a.npanels, col_tiles);
   const Tuning &t = tuning();
