@@ -37,9 +37,10 @@ int resolve_opts(const hg_plan_opts *in, hg::Opts &o) {
     o.flags = in->flags;
     if (in->t_big > 0) o.t_big = in->t_big;
     if (in->fused_tile_bytes > 0) o.fused_tile_bytes = in->fused_tile_bytes;
+    if (in->fused_stage_bytes > 0) o.fused_stage_bytes = in->fused_stage_bytes;
   }
   if (o.short_max > o.panel_nnz || o.split_len < o.short_max || o.panel_rows > 4096 ||
-      o.panel_nnz > 16384 || o.fused_tile_bytes > 65536) {
+      o.panel_nnz > 16384 || o.fused_tile_bytes > 65536 || o.fused_stage_bytes > 131072) {
     hg::set_error("hg_plan_opts: need short_max <= panel_nnz <= 16384, split_len >= short_max, panel_rows <= 4096, fused_tile_bytes <= 65536");
     return HG_ERR_INVALID;
   }
@@ -117,26 +118,36 @@ void fused_free(hg::FusedSched &f) {
   sched_free(f.hub_sched);
 }
 
-int fused_cap(const hg_plan *p, int32_t F, bool vec4) {
+// Capacities of a fused panel for feature width F.  LDS-DMA kernel: the landing
+// zone holds mem_cap gathered rows (a multiple of 64 so that whole DMA
+// instructions fit), slots = mem_cap / 2.  Register-staged kernel: a tile of
+// `cap` rows, 4 entries per slot on average.
+void fused_caps(const hg_plan *p, int32_t F, bool vec4, bool dma, int32_t &cap, int32_t &mem_cap) {
   const int row_bytes = hg::fused_tile_row_floats(F, vec4) * 4;
-  int cap = p->opts.fused_tile_bytes / row_bytes;
-  cap = std::max(16, std::min(256, cap));
-  int p2 = 16;
-  while (p2 * 2 <= cap) p2 *= 2;
-  return p2;
+  if (dma) {
+    mem_cap = std::max(64, std::min(2048, p->opts.fused_stage_bytes / row_bytes / 64 * 64));
+    cap = std::max(16, mem_cap / 2);
+  } else {
+    int c = std::max(16, std::min(256, p->opts.fused_tile_bytes / row_bytes));
+    cap = 16;
+    while (cap * 2 <= c) cap *= 2;
+    mem_cap = cap * 4;
+  }
 }
 
 // The F-dependent part of the plan, built on first use (guarded by the plan's mutex).
-int get_fused(const hg_plan *cp, int32_t F, bool vec4, const hg::FusedSched **out) {
+int get_fused(const hg_plan *cp, int32_t F, bool vec4, bool dma, const hg::FusedSched **out) {
   hg_plan *p = const_cast<hg_plan *>(cp);
-  const int cap = fused_cap(p, F, vec4);
+  int32_t cap, mem_cap;
+  fused_caps(p, F, vec4, dma, cap, mem_cap);
+  const int64_t key = (int64_t)cap * 1000000 + mem_cap;
   std::lock_guard<std::mutex> lock(p->fused_mu);
-  auto it = p->fused.find(cap);
+  auto it = p->fused.find(key);
   if (it == p->fused.end()) {
     hg::FusedSched f;
     try {
       hg::build_fused(p->N, p->M, p->ptr_t.data(), p->ind_t.data(), p->ptr_v.data(), p->ind_v.data(),
-                      p->opts, cap, f);
+                      p->opts, cap, mem_cap, f);
     } catch (const std::bad_alloc &) {
       hg::set_error("fused schedule: host allocation failed");
       return HG_ERR_NOMEM;
@@ -154,7 +165,7 @@ int get_fused(const hg_plan *cp, int32_t F, bool vec4, const hg::FusedSched **ou
       fused_free(f);
       return rc;
     }
-    it = p->fused.emplace(cap, std::move(f)).first;
+    it = p->fused.emplace(key, std::move(f)).first;
   }
   *out = &it->second;
   return HG_OK;
@@ -397,7 +408,7 @@ int hg_plan_prepare(const hg_plan *p, int32_t F, hg_fused_info *info) {
     return HG_ERR_INVALID;
   }
   const hg::FusedSched *f = nullptr;
-  int rc = get_fused(p, F, F % 4 == 0, &f);
+  int rc = get_fused(p, F, F % 4 == 0, hg::fused_use_dma(), &f);
   if (rc != HG_OK) return rc;
   if (info) {
     info->cap = f->cap;
@@ -501,7 +512,8 @@ int hg_aggr_fused_f32(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
   if (variant == HG_VARIANT_FUSED) {
     const bool vec4 = (F % 4 == 0) && aligned16(X) && aligned16(Y) && aligned16(Xe);
     const hg::FusedSched *f = nullptr;
-    if ((rc = get_fused(plan, F, vec4, &f)) != HG_OK) return rc;
+    const bool dma = hg::fused_use_dma();
+    if ((rc = get_fused(plan, F, vec4, dma, &f)) != HG_OK) return rc;
     // (a) materialised hyperedges (long ones, and those of hub vertices): Xe_mat rows
     if (f->n_mat > 0) {
       rc = run_sched(plan, f->mat_sched, F, f->d_mat_ptr, f->d_mat_ind, X, degE, W, f->d_mat_eid,
@@ -536,6 +548,7 @@ int hg_aggr_fused_f32(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
     a.mem_cap = f->mem_cap;
     a.vslot_cap = f->vslot_cap;
     a.xcd_remap = (plan->opts.flags & HG_PLAN_NO_XCD_REMAP) ? 0 : 1;
+    a.dma = dma ? 1 : 0;
     hipError_t e = hg::launch_fused(a, vec4, s);
     if (e != hipSuccess) return hip_fail("fused_panel launch", e);
     return HG_OK;

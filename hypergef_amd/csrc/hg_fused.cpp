@@ -14,11 +14,11 @@ namespace hg {
 
 void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_t,
                  const int32_t *ptr_v, const int32_t *ind_v, const Opts &o, int32_t cap,
-                 FusedSched &f) {
+                 int32_t mem_cap, FusedSched &f) {
   f = FusedSched();
   f.cap = cap;
   f.rows_cap = cap;
-  f.mem_cap = cap * 4;
+  f.mem_cap = mem_cap;
   f.vslot_cap = cap * 2;
   f.t_big = std::max(1, std::min(o.t_big, f.mem_cap));
   // a single row must always fit into an empty panel

@@ -87,7 +87,8 @@ struct Opts {
   int32_t panel_nnz = 1024;
   int32_t flags = 0;
   int32_t t_big = 8;           // fused: recompute hyperedges of at most this many members
-  int32_t fused_tile_bytes = 16384;  // fused: LDS tile budget -> slot capacity
+  int32_t fused_tile_bytes = 16384;  // fused (register-staged kernel): LDS tile budget -> slot capacity
+  int32_t fused_stage_bytes = 32768;  // fused (LDS-DMA kernel): LDS landing zone for gathered rows
 };
 
 void set_error(const std::string &msg);
@@ -104,7 +105,7 @@ void transpose_csr(int32_t nrows, int32_t ncols, const int32_t *ptr,
 void build_sched(int32_t nrows, const int32_t *ptr, const Opts &o, Sched &s);
 void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_t,
                  const int32_t *ptr_v, const int32_t *ind_v, const Opts &o, int32_t cap,
-                 FusedSched &f);
+                 int32_t mem_cap, FusedSched &f);
 
 }  // namespace hg
 
@@ -116,7 +117,7 @@ struct hg_plan {
   std::vector<int32_t> ptr_v, ind_v;  // H CSR (vertex -> hyperedges), host
   int32_t *d_ptr_v = nullptr, *d_ind_v = nullptr;
   hg::Sched sched[2];  // [0]: H_T rows = hyperedges, [1]: H rows = vertices
-  std::map<int32_t, hg::FusedSched> fused;  // keyed by slot capacity (depends on F)
+  std::map<int64_t, hg::FusedSched> fused;  // keyed by (slot, entry) capacity: depends on F
   std::mutex fused_mu;
   int64_t device_bytes = 0;
   int device = -1;

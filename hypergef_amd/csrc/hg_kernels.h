@@ -37,6 +37,7 @@ struct FusedArgs {
   int32_t F;
   int32_t cap, rows_cap, mem_cap, vslot_cap;
   int32_t xcd_remap;
+  int32_t dma;  // 1: LDS-DMA kernel, 0: register-staged kernel
 };
 
 struct PushArgs {
@@ -52,6 +53,7 @@ hipError_t launch_gather(const GatherArgs &a, int nfix, const Fixup *fixups, boo
                          hipStream_t stream);
 hipError_t launch_fused(const FusedArgs &a, bool vec4, hipStream_t stream);
 int fused_tile_row_floats(int F, bool vec4);
+bool fused_use_dma();
 hipError_t launch_push(const PushArgs &a, hipStream_t stream);
 
 }  // namespace hg

@@ -334,6 +334,118 @@ __global__ __launch_bounds__(BS) void fused_panel_kernel(const FusedArgs a) {
   }
 }
 
+// LDS-DMA form of the fused panel kernel.  Every member row of every slot of the
+// panel is gathered by `global_load_lds` (per-lane source address, LDS
+// destination = wave-uniform base + lane * 16 B, so one wave instruction lands
+// 64/LPR consecutive entries as consecutive rows of the landing zone) with no
+// VGPR staging: all of a panel's gathers are in flight at once instead of U per
+// lane.  The chain per workgroup is descriptor -> lists -> rows -> store.
+// Slot sums are then formed from LDS in entry order and written over the slot's
+// first entry row, which doubles as the hyperedge tile for hop 2.
+template <int LPR, int VEC>
+__global__ __launch_bounds__(256) void fused_dma_kernel(const FusedArgs a) {
+  constexpr int BS = 256;
+  constexpr int NG = BS / LPR;
+  constexpr int TW = LPR * VEC;   // row stride of the landing zone in floats
+  constexpr int EPI = 64 / LPR;   // entries per DMA wave instruction
+  using V = Vec<VEC>;
+  extern __shared__ int32_t smem[];
+  const int tid = threadIdx.x;
+  const int gl = tid & (LPR - 1);
+  const int lcol = gl * VEC;
+  const int col = blockIdx.y * TW + lcol;
+  const bool col_ok = col < a.F;
+  const int64_t F = a.F;
+  int b = blockIdx.x;
+  if (a.xcd_remap) {
+    const int x = b & 7, i = b >> 3;
+    const int cpx = a.npanels >> 3, rem = a.npanels & 7;
+    b = x * cpx + (x < rem ? x : rem) + i;
+  }
+  const FPanel pn = a.panels[b];
+
+  float *stage = reinterpret_cast<float *>(smem);             // [mem_cap * TW]
+  int32_t *soff = smem + a.mem_cap * TW;                       // [cap + 1]
+  float *sA = reinterpret_cast<float *>(soff + a.cap + 1);     // [cap]
+  float *sB = sA + a.cap;                                      // [cap]
+  int32_t *spm = reinterpret_cast<int32_t *>(sB + a.cap);      // [mem_cap]
+  int32_t *sptr = spm + a.mem_cap;                             // [rows_cap + 1]
+  float *sdeg = reinterpret_cast<float *>(sptr + a.rows_cap + 1);   // [rows_cap]
+  int32_t *srow = reinterpret_cast<int32_t *>(sdeg + a.rows_cap);   // [rows_cap]
+  int32_t *seid = srow + a.rows_cap;                           // [cap]
+  uint16_t *svs = reinterpret_cast<uint16_t *>(seid + a.cap);  // [vslot_cap]
+
+  for (int i = tid; i <= pn.nslots; i += BS) soff[i] = a.soff[pn.sbase + i];
+  for (int i = tid; i < pn.npm; i += BS) spm[i] = a.pmem[pn.pm0 + i];
+  if (tid == 0) sptr[0] = 0;
+  for (int i = tid; i < pn.nrows; i += BS) {
+    sptr[i + 1] = a.pend[pn.r0 + i];
+    srow[i] = a.prow[pn.r0 + i];
+  }
+  for (int i = tid; i < pn.nvs; i += BS) svs[i] = a.pvs[pn.v0 + i];
+  if (a.degE || a.W)
+    for (int i = tid; i < pn.nslots; i += BS) seid[i] = a.slot_eid[pn.eid0 + i];
+  __syncthreads();
+
+  // ---- all row gathers of the panel, straight into LDS
+  {
+    const int wave = tid >> 6, lane = tid & 63;
+    const int nchunks = (pn.npm + EPI - 1) / EPI;
+    for (int c = wave; c < nchunks; c += BS / 64) {
+      const int e = min(c * EPI + lane / LPR, pn.npm - 1);
+      const int ent = spm[e];
+      const float *base = ent < 0 ? a.Xe_mat : a.X;
+      const float *src = base + (int64_t)(ent & 0x7fffffff) * F + col;
+      float *dst = stage + (size_t)c * EPI * TW;  // hardware adds lane * VEC * 4 bytes
+      if (col_ok) {
+        // the size argument must be a literal (1, 2, 4, 12 or 16)
+        if constexpr (VEC == 4)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                           (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        else
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                           (__attribute__((address_space(3))) void *)dst, 4, 0, 0);
+      }
+    }
+    // the scale gathers ride in the same round trip
+    if (a.degE || a.W)
+      for (int i = tid; i < pn.nslots; i += BS) {
+        const int e = seid[i];  // -1: materialised row, already scaled
+        sA[i] = (a.degE && e >= 0) ? a.degE[e] : 1.f;
+        sB[i] = (a.W && e >= 0) ? a.W[e] : 1.f;
+      }
+    if (a.degV)
+      for (int i = tid; i < pn.nrows; i += BS) sdeg[i] = a.degV[srow[i]];
+  }
+  __syncthreads();  // drains the DMA (vmcnt(0)) and publishes the scales
+
+  const int g = tid / LPR;
+  {  // ---- hop 1: slot sums, in entry order, written over the slot's first row
+    const int spg = (pn.nslots + NG - 1) / NG;
+    const int k0 = min(g * spg, pn.nslots), k1 = min(k0 + spg, pn.nslots);
+    for (int k = k0; k < k1; k++) {
+      const int pb = soff[k], pe = soff[k + 1];
+      V acc = V::zero();
+      for (int p = pb; p < pe; p++) acc.add(V::load(stage + p * TW + lcol));
+      if (a.degE) acc.mul(sA[k]);
+      if (a.W) acc.mul(sB[k]);
+      acc.store(stage + pb * TW + lcol);
+    }
+  }
+  __syncthreads();
+  {  // ---- hop 2: vertices <- slot rows
+    const int rpg = (pn.nrows + NG - 1) / NG;
+    const int r0 = min(g * rpg, pn.nrows), r1 = min(r0 + rpg, pn.nrows);
+    for (int r = r0; r < r1; r++) {
+      V acc = V::zero();
+      const int pb = sptr[r], pe = sptr[r + 1];
+      for (int p = pb; p < pe; p++) acc.add(V::load(stage + soff[svs[p]] * TW + lcol));
+      if (a.degV && pe > pb) acc.mul(sdeg[r]);
+      if (col_ok) acc.store(a.Y + (int64_t)srow[r] * F + col);
+    }
+  }
+}
+
 // The reference's register-fused scheme on wave64: LPR lanes = LPR feature
 // columns of one task, 64/LPR tasks per wave.  Gather-sum the read partition,
 // scale by degE*W, scatter acc*degV[v] to the write partition with hardware
@@ -382,6 +494,7 @@ struct Tuning {
   int pipe = 0;
   int fused_bs = 256;
   int fused_u = 4;
+  int fused_dma = 1;
 };
 // Experiment knobs (HG_UNROLL = 4|8, HG_PIPE = 0|1), read once.
 static const Tuning &tuning() {
@@ -391,6 +504,7 @@ static const Tuning &tuning() {
     if (const char *e = getenv("HG_PIPE")) x.pipe = atoi(e) != 0;
     if (const char *e = getenv("HG_FUSED_BS")) x.fused_bs = atoi(e);
     if (const char *e = getenv("HG_FUSED_U")) x.fused_u = atoi(e);
+    if (const char *e = getenv("HG_FUSED_DMA")) x.fused_dma = atoi(e) != 0;
     return x;
   }();
   return t;
@@ -454,6 +568,13 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
                      (size_t)a.vslot_cap * 2 + 16;
   const dim3 grid(a.npanels, col_tiles);
   const Tuning &t = tuning();
+  if (a.dma) {
+    const size_t lds_dma = (size_t)a.mem_cap * TW * 4 +
+                           (size_t)(a.cap + 1 + 2 * a.cap + a.mem_cap + a.rows_cap + 1 + 2 * a.rows_cap + a.cap) * 4 +
+                           (size_t)a.vslot_cap * 2 + 16;
+    hipLaunchKernelGGL((fused_dma_kernel<LPR, VEC>), grid, dim3(256), lds_dma, stream, a);
+    return hipGetLastError();
+  }
 #define HG_FUSED(UU, BB) \
   hipLaunchKernelGGL((fused_panel_kernel<LPR, VEC, UU, BB>), grid, dim3(BB), lds, stream, a)
   if (t.fused_bs == 512) {
@@ -485,6 +606,8 @@ hipError_t launch_fused(const FusedArgs &a, bool vec4, hipStream_t stream) {
 #undef HG_CASE
   return hipErrorInvalidValue;
 }
+
+bool fused_use_dma() { return tuning().fused_dma != 0; }
 
 // floats per LDS tile row for feature width F (what launch_fused will use)
 int fused_tile_row_floats(int F, bool vec4) {
