@@ -446,6 +446,218 @@ __global__ __launch_bounds__(256) void fused_dma_kernel(const FusedArgs a) {
   }
 }
 
+// Persistent, software-pipelined form of fused_panel_kernel.  A workgroup walks a
+// strided sequence of its XCD's panels; while it gathers and sums panel i, the
+// lists of panel i+1 are already in flight (into registers, written to LDS when
+// panel i is done) and the descriptor of panel i+2 is being fetched, so the
+// descriptor -> lists -> rows dependency chain is paid once per workgroup, not
+// once per panel.  Arithmetic identical to fused_panel_kernel.
+template <int LPR, int VEC, int U>
+__global__ __launch_bounds__(256) void fused_persist_kernel(const FusedArgs a) {
+  constexpr int BS = 256;
+  constexpr int NG = BS / LPR;
+  constexpr int TW = LPR * VEC;
+  // register prefetch capacity per thread (cap <= 256, mem_cap <= 1024, vslot_cap <= 512)
+  constexpr int NK_SOFF = 2, NK_PM = 4, NK_ROW = 1, NK_VS = 2;
+  using V = Vec<VEC>;
+  extern __shared__ int32_t smem[];
+  const int tid = threadIdx.x;
+  const int gl = tid & (LPR - 1);
+  const int lcol = gl * VEC;
+  const int col = blockIdx.y * TW + lcol;
+  const bool col_ok = col < a.F;
+  const int64_t F = a.F;
+
+  // this workgroup's panel sequence: first, first + step, ... < last
+  int first, step, last;
+  {
+    const int w = blockIdx.x, G = gridDim.x;
+    if (a.xcd_remap && G >= 8) {
+      const int x = w & 7, j = w >> 3;
+      const int J = (G - x + 7) >> 3;  // workgroups of this XCD class
+      const int cpx = a.npanels >> 3, rem = a.npanels & 7;
+      const int start = x * cpx + (x < rem ? x : rem);
+      first = start + j;
+      step = J;
+      last = start + cpx + (x < rem ? 1 : 0);
+    } else {
+      first = w;
+      step = G;
+      last = a.npanels;
+    }
+  }
+  if (first >= last) return;
+
+  float *tile = reinterpret_cast<float *>(smem);            // [cap * TW]
+  int32_t *soff = smem + a.cap * TW;                         // [cap + 1]
+  float *sA = reinterpret_cast<float *>(soff + a.cap + 1);   // [cap]
+  float *sB = sA + a.cap;                                    // [cap]
+  int32_t *spm = reinterpret_cast<int32_t *>(sB + a.cap);    // [mem_cap]
+  int32_t *sptr = spm + a.mem_cap;                           // [rows_cap + 1]
+  float *sdeg = reinterpret_cast<float *>(sptr + a.rows_cap + 1);  // [rows_cap]
+  int32_t *srow = reinterpret_cast<int32_t *>(sdeg + a.rows_cap);  // [rows_cap]
+  uint16_t *svs = reinterpret_cast<uint16_t *>(srow + a.rows_cap);  // [vslot_cap]
+
+  const bool weighted = a.degE || a.W || a.degV;
+
+  struct Lists {  // one panel's lists, strided over the workgroup's threads
+    int32_t off[NK_SOFF], pm[NK_PM], pend[NK_ROW], row[NK_ROW], eid[NK_SOFF];
+    uint16_t vs[NK_VS];
+  };
+  auto fetch = [&](const FPanel &pn, Lists &L) {
+#pragma unroll
+    for (int k = 0; k < NK_SOFF; k++) {
+      const int i = tid + k * BS;
+      L.off[k] = i <= pn.nslots ? a.soff[pn.sbase + i] : 0;
+      L.eid[k] = (weighted && i < pn.nslots) ? a.slot_eid[pn.eid0 + i] : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < NK_PM; k++) {
+      const int i = tid + k * BS;
+      L.pm[k] = i < pn.npm ? a.pmem[pn.pm0 + i] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < NK_ROW; k++) {
+      const int i = tid + k * BS;
+      L.pend[k] = i < pn.nrows ? a.pend[pn.r0 + i] : 0;
+      L.row[k] = i < pn.nrows ? a.prow[pn.r0 + i] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < NK_VS; k++) {
+      const int i = tid + k * BS;
+      L.vs[k] = i < pn.nvs ? a.pvs[pn.v0 + i] : (uint16_t)0;
+    }
+  };
+  // second-level gathers (scales), issued as soon as the ids are in registers
+  struct Scales {
+    float sa[NK_SOFF], sb[NK_SOFF], sd[NK_ROW];
+  };
+  auto fetch_scales = [&](const FPanel &pn, const Lists &L, Scales &S) {
+#pragma unroll
+    for (int k = 0; k < NK_SOFF; k++) {
+      const int i = tid + k * BS;
+      const int e = L.eid[k];
+      S.sa[k] = (a.degE && i < pn.nslots && e >= 0) ? a.degE[e] : 1.f;
+      S.sb[k] = (a.W && i < pn.nslots && e >= 0) ? a.W[e] : 1.f;
+    }
+#pragma unroll
+    for (int k = 0; k < NK_ROW; k++) {
+      const int i = tid + k * BS;
+      S.sd[k] = (a.degV && i < pn.nrows) ? a.degV[L.row[k]] : 1.f;
+    }
+  };
+  auto commit = [&](const FPanel &pn, const Lists &L, const Scales &S) {
+#pragma unroll
+    for (int k = 0; k < NK_SOFF; k++) {
+      const int i = tid + k * BS;
+      if (i <= pn.nslots) soff[i] = L.off[k];
+      if (weighted && i < pn.nslots) {
+        sA[i] = S.sa[k];
+        sB[i] = S.sb[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NK_PM; k++) {
+      const int i = tid + k * BS;
+      if (i < pn.npm) spm[i] = L.pm[k];
+    }
+    if (tid == 0) sptr[0] = 0;
+#pragma unroll
+    for (int k = 0; k < NK_ROW; k++) {
+      const int i = tid + k * BS;
+      if (i < pn.nrows) {
+        sptr[i + 1] = L.pend[k];
+        srow[i] = L.row[k];
+        if (weighted) sdeg[i] = S.sd[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NK_VS; k++) {
+      const int i = tid + k * BS;
+      if (i < pn.nvs) svs[i] = L.vs[k];
+    }
+  };
+
+  const int g = tid / LPR;
+  FPanel pn = a.panels[first];
+  Lists L;
+  Scales S;
+  fetch(pn, L);
+  if (weighted) fetch_scales(pn, L, S);
+  commit(pn, L, S);
+  int nxt = first + step;
+  FPanel pn1 = a.panels[min(nxt, a.npanels - 1)];
+  __syncthreads();
+
+  for (;; nxt += step) {
+    const bool has_next = nxt < last;
+    // descriptor two panels ahead, lists one panel ahead
+    const FPanel pn2 = a.panels[min(nxt + step, a.npanels - 1)];
+    if (has_next) fetch(pn1, L);
+
+    {  // ---- hop 1: slots -> LDS tile
+      const int spg = (pn.nslots + NG - 1) / NG;
+      int k = min(g * spg, pn.nslots);
+      const int ke = min(k + spg, pn.nslots);
+      if (k < ke) {
+        auto flush = [&](int slot, V acc) {
+          if (a.degE) acc.mul(sA[slot]);
+          if (a.W) acc.mul(sB[slot]);
+          acc.store(tile + slot * TW + lcol);
+        };
+        int pos = soff[k];
+        const int stop = soff[ke];
+        int slot_end = soff[k + 1];
+        V acc = V::zero();
+        while (pos < stop) {
+          const int n = min(U, stop - pos);
+          V v[U];
+#pragma unroll
+          for (int j = 0; j < U; j++) {
+            const int ent = spm[pos + min(j, n - 1)];
+            const float *base = ent < 0 ? a.Xe_mat : a.X;
+            const int64_t idx = ent & 0x7fffffff;
+            v[j] = col_ok ? V::load(base + idx * F + col) : V::zero();
+          }
+#pragma unroll
+          for (int j = 0; j < U; j++) {
+            if (j < n) {
+              while (slot_end <= pos + j) {
+                flush(k, acc);
+                acc = V::zero();
+                k++;
+                slot_end = soff[k + 1];
+              }
+              acc.add(v[j]);
+            }
+          }
+          pos += n;
+        }
+        flush(k, acc);
+      }
+    }
+    if (has_next && weighted) fetch_scales(pn1, L, S);  // ids have landed by now
+    __syncthreads();
+    {  // ---- hop 2: vertices <- LDS tile
+      const int rpg = (pn.nrows + NG - 1) / NG;
+      const int r0 = min(g * rpg, pn.nrows), r1 = min(r0 + rpg, pn.nrows);
+      for (int r = r0; r < r1; r++) {
+        V acc = V::zero();
+        const int pb = sptr[r], pe = sptr[r + 1];
+        for (int p = pb; p < pe; p++) acc.add(V::load(tile + (int)svs[p] * TW + lcol));
+        if (a.degV && pe > pb) acc.mul(sdeg[r]);
+        if (col_ok) acc.store(a.Y + (int64_t)srow[r] * F + col);
+      }
+    }
+    if (!has_next) break;
+    __syncthreads();  // everyone is done with this panel's lists and tile
+    commit(pn1, L, S);
+    pn = pn1;
+    pn1 = pn2;
+    __syncthreads();
+  }
+}
+
 // The reference's register-fused scheme on wave64: LPR lanes = LPR feature
 // columns of one task, 64/LPR tasks per wave.  Gather-sum the read partition,
 // scale by degE*W, scatter acc*degV[v] to the write partition with hardware
@@ -494,7 +706,9 @@ struct Tuning {
   int pipe = 0;
   int fused_bs = 256;
   int fused_u = 4;
-  int fused_dma = 1;
+  int fused_dma = 0;
+  int fused_persist = 1;
+  int fused_grid = 0;
 };
 // Experiment knobs (HG_UNROLL = 4|8, HG_PIPE = 0|1), read once.
 static const Tuning &tuning() {
@@ -505,6 +719,8 @@ static const Tuning &tuning() {
     if (const char *e = getenv("HG_FUSED_BS")) x.fused_bs = atoi(e);
     if (const char *e = getenv("HG_FUSED_U")) x.fused_u = atoi(e);
     if (const char *e = getenv("HG_FUSED_DMA")) x.fused_dma = atoi(e) != 0;
+    if (const char *e = getenv("HG_FUSED_PERSIST")) x.fused_persist = atoi(e) != 0;
+    if (const char *e = getenv("HG_FUSED_GRID")) x.fused_grid = atoi(e);
     return x;
   }();
   return t;
@@ -575,16 +791,29 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
     hipLaunchKernelGGL((fused_dma_kernel<LPR, VEC>), grid, dim3(256), lds_dma, stream, a);
     return hipGetLastError();
   }
-#define HG_FUSED(UU, BB) \
-  hipLaunchKernelGGL((fused_panel_kernel<LPR, VEC, UU, BB>), grid, dim3(BB), lds, stream, a)
-  if (t.fused_bs == 512) {
-    if (t.fused_u == 8) HG_FUSED(8, 512); else HG_FUSED(4, 512);
-  } else if (t.fused_bs == 1024) {
-    if (t.fused_u == 8) HG_FUSED(8, 1024); else HG_FUSED(4, 1024);
-  } else {
-    if (t.fused_u == 8) HG_FUSED(8, 256); else HG_FUSED(4, 256);
+  if (t.fused_persist && a.cap <= 256 && a.mem_cap <= 1024 && a.rows_cap <= 256 && a.vslot_cap <= 512) {
+    // persistent grid: as many workgroups as the chip holds at once (an oversized grid
+    // would only queue: workgroups never wait for each other)
+    static int num_cu = 0;
+    if (num_cu == 0) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess ||
+          hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || num_cu <= 0)
+        num_cu = 256;
+    }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_persist_kernel<LPR, VEC, 4>, 256, lds) !=
+            hipSuccess || per_cu <= 0)
+      per_cu = 4;
+    const int want = t.fused_grid > 0 ? t.fused_grid : num_cu * per_cu;
+    const int nwg = std::min(a.npanels, want);
+    hipLaunchKernelGGL((fused_persist_kernel<LPR, VEC, 4>), dim3(nwg, col_tiles), dim3(256), lds, stream, a);
+    return hipGetLastError();
   }
-#undef HG_FUSED
+  if (t.fused_u == 8)
+    hipLaunchKernelGGL((fused_panel_kernel<LPR, VEC, 8, 256>), grid, dim3(256), lds, stream, a);
+  else
+    hipLaunchKernelGGL((fused_panel_kernel<LPR, VEC, 4, 256>), grid, dim3(256), lds, stream, a);
   return hipGetLastError();
 }
 
