@@ -38,6 +38,7 @@ struct FusedArgs {
   int32_t cap, rows_cap, mem_cap, vslot_cap;
   int32_t xcd_remap;
   int32_t dma;  // 1: LDS-DMA kernel, 0: register-staged kernel
+  int32_t debug = 0;  // ablation bits (experiments only)
 };
 
 struct PushArgs {

@@ -277,9 +277,10 @@ __global__ __launch_bounds__(BS) void fused_panel_kernel(const FusedArgs a) {
     }
   }
   __syncthreads();
+  if (a.debug & 16) return;  // ablation: descriptor + lists only
 
   const int g = tid / LPR;
-  {  // ---- hop 1: slots -> LDS tile
+  if (!(a.debug & 4)) {  // ---- hop 1: slots -> LDS tile
     const int spg = (pn.nslots + NG - 1) / NG;
     int k = min(g * spg, pn.nslots);
     const int ke = min(k + spg, pn.nslots);
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(BS) void fused_panel_kernel(const FusedArgs a) {
           const int ent = spm[pos + min(j, n - 1)];
           const float *base = ent < 0 ? a.Xe_mat : a.X;
           const int64_t idx = ent & 0x7fffffff;
-          v[j] = col_ok ? V::load(base + idx * F + col) : V::zero();
+          v[j] = (col_ok && !(a.debug & 1)) ? V::load(base + idx * F + col) : V::zero();
         }
 #pragma unroll
         for (int j = 0; j < U; j++) {
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(BS) void fused_panel_kernel(const FusedArgs a) {
     }
   }
   __syncthreads();
-  {  // ---- hop 2: vertices <- LDS tile
+  if (!(a.debug & 8)) {  // ---- hop 2: vertices <- LDS tile
     const int rpg = (pn.nrows + NG - 1) / NG;
     const int r0 = min(g * rpg, pn.nrows), r1 = min(r0 + rpg, pn.nrows);
     for (int r = r0; r < r1; r++) {
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(BS) void fused_panel_kernel(const FusedArgs a) {
       const int pb = sptr[r], pe = sptr[r + 1];
       for (int p = pb; p < pe; p++) acc.add(V::load(tile + (int)svs[p] * TW + lcol));
       if (a.degV && pe > pb) acc.mul(sdeg[r]);
-      if (col_ok) acc.store(a.Y + (int64_t)srow[r] * F + col);
+      if (col_ok && !(a.debug & 2)) acc.store(a.Y + (int64_t)srow[r] * F + col);
     }
   }
 }
@@ -709,6 +710,7 @@ struct Tuning {
   int fused_dma = 0;
   int fused_persist = 1;
   int fused_grid = 0;
+  int fused_debug = 0;  // ablation bits for fused_panel_kernel (timing experiments only)
 };
 // Experiment knobs (HG_UNROLL = 4|8, HG_PIPE = 0|1), read once.
 static const Tuning &tuning() {
@@ -721,6 +723,7 @@ static const Tuning &tuning() {
     if (const char *e = getenv("HG_FUSED_DMA")) x.fused_dma = atoi(e) != 0;
     if (const char *e = getenv("HG_FUSED_PERSIST")) x.fused_persist = atoi(e) != 0;
     if (const char *e = getenv("HG_FUSED_GRID")) x.fused_grid = atoi(e);
+    if (const char *e = getenv("HG_FUSED_DEBUG")) x.fused_debug = atoi(e);
     return x;
   }();
   return t;
@@ -810,10 +813,12 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
     hipLaunchKernelGGL((fused_persist_kernel<LPR, VEC, 4>), dim3(nwg, col_tiles), dim3(256), lds, stream, a);
     return hipGetLastError();
   }
+  FusedArgs ad = a;
+  ad.debug = t.fused_debug;
   if (t.fused_u == 8)
-    hipLaunchKernelGGL((fused_panel_kernel<LPR, VEC, 8, 256>), grid, dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((fused_panel_kernel<LPR, VEC, 8, 256>), grid, dim3(256), lds, stream, ad);
   else
-    hipLaunchKernelGGL((fused_panel_kernel<LPR, VEC, 4, 256>), grid, dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((fused_panel_kernel<LPR, VEC, 4, 256>), grid, dim3(256), lds, stream, ad);
   return hipGetLastError();
 }
 
