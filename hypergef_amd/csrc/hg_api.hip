@@ -425,6 +425,12 @@ int hg_plan_prepare(const hg_plan *p, int32_t F, hg_fused_info *info) {
   return HG_OK;
 }
 
+// Diagnostic only (not declared in hg_aggr.h): per-phase cycle counters of the
+// fused kernel when HG_FUSED_DEBUG has bit 32 set.
+__attribute__((visibility("default"))) int hg_debug_read_stamps(unsigned long long *out8, int reset) {
+  return hg::read_stamps(out8, reset != 0) == hipSuccess ? HG_OK : HG_ERR_HIP;
+}
+
 size_t hg_plan_workspace_bytes(const hg_plan *p, int32_t F) {
   if (!p || F <= 0) return 0;
   return carve(p, F).total;

@@ -55,6 +55,7 @@ hipError_t launch_gather(const GatherArgs &a, int nfix, const Fixup *fixups, boo
 hipError_t launch_fused(const FusedArgs &a, bool vec4, hipStream_t stream);
 int fused_tile_row_floats(int F, bool vec4);
 bool fused_use_dma();
+hipError_t read_stamps(unsigned long long *out, bool reset);
 hipError_t launch_push(const PushArgs &a, hipStream_t stream);
 
 }  // namespace hg

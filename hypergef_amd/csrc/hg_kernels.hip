@@ -229,6 +229,18 @@ __global__ __launch_bounds__(256) void fixup_rows_kernel(const GatherArgs a, con
 //          vertex's hyperedges in H-CSR order, scales by degV and stores Y.
 // Same arithmetic and order as the two-phase path (and the CPU reference), but
 // the hyperedge feature rows never leave the CU.
+// Diagnostic stamps (debug bit 32): lane 0 of every wave adds the cycles since
+// the previous stamp to a global counter per phase.  Never on in production.
+__device__ unsigned long long hg_stamps[8];
+#define HG_STAMP(i)                                                        \
+  do {                                                                     \
+    if (stamp) {                                                           \
+      const unsigned long long t1 = __builtin_amdgcn_s_memtime();          \
+      atomicAdd(&hg_stamps[i], t1 - t0);                                   \
+      t0 = t1;                                                             \
+    }                                                                      \
+  } while (0)
+
 template <int LPR, int VEC, int U, int BS>
 __global__ __launch_bounds__(BS) void fused_panel_kernel(const FusedArgs a) {
   constexpr int NG = BS / LPR;
@@ -247,7 +259,10 @@ __global__ __launch_bounds__(BS) void fused_panel_kernel(const FusedArgs a) {
     const int cpx = a.npanels >> 3, rem = a.npanels & 7;
     b = x * cpx + (x < rem ? x : rem) + i;
   }
+  const bool stamp = (a.debug & 32) && (threadIdx.x & 63) == 0;
+  unsigned long long t0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
   const FPanel pn = a.panels[b];
+  HG_STAMP(0);
 
   float *tile = reinterpret_cast<float *>(smem);            // [cap * TW]
   int32_t *soff = smem + a.cap * TW;                         // [cap + 1]
@@ -276,7 +291,9 @@ __global__ __launch_bounds__(BS) void fused_panel_kernel(const FusedArgs a) {
       sB[i] = (a.W && e >= 0) ? a.W[e] : 1.0f;
     }
   }
+  HG_STAMP(1);
   __syncthreads();
+  HG_STAMP(2);
   if (a.debug & 16) return;  // ablation: descriptor + lists only
 
   const int g = tid / LPR;
@@ -321,7 +338,9 @@ __global__ __launch_bounds__(BS) void fused_panel_kernel(const FusedArgs a) {
       flush(k, acc);  // every slot has at least one entry, so the last one is still open
     }
   }
+  HG_STAMP(3);
   __syncthreads();
+  HG_STAMP(4);
   if (!(a.debug & 8)) {  // ---- hop 2: vertices <- LDS tile
     const int rpg = (pn.nrows + NG - 1) / NG;
     const int r0 = min(g * rpg, pn.nrows), r1 = min(r0 + rpg, pn.nrows);
@@ -333,6 +352,7 @@ __global__ __launch_bounds__(BS) void fused_panel_kernel(const FusedArgs a) {
       if (col_ok && !(a.debug & 2)) acc.store(a.Y + (int64_t)srow[r] * F + col);
     }
   }
+  HG_STAMP(5);
 }
 
 // LDS-DMA form of the fused panel kernel.  Every member row of every slot of the
@@ -842,6 +862,15 @@ hipError_t launch_fused(const FusedArgs &a, bool vec4, hipStream_t stream) {
 }
 
 bool fused_use_dma() { return tuning().fused_dma != 0; }
+
+hipError_t read_stamps(unsigned long long *out, bool reset) {
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(hg_stamps), sizeof(hg_stamps));
+  if (e == hipSuccess && reset) {
+    unsigned long long z[8] = {0};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(hg_stamps), z, sizeof(z));
+  }
+  return e;
+}
 
 // floats per LDS tile row for feature width F (what launch_fused will use)
 int fused_tile_row_floats(int F, bool vec4) {

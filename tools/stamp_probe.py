@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Per-phase cycle shares of fused_panel_kernel (diagnostic build path: HG_FUSED_DEBUG=32)."""
+import ctypes, os, sys
+os.environ["HG_FUSED_PERSIST"] = "0"
+os.environ["HG_FUSED_DEBUG"] = "32"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from hypergef_amd import plan as planmod, synth, _lib
+dev = "cuda:0"
+K, F = 1024, 32
+inc = synth.replicate_block_diagonal(synth.cora_shape(), K)
+ptr, ind = torch.from_numpy(inc.csrptr).to(dev), torch.from_numpy(inc.colind).to(dev)
+X = torch.rand(inc.N, F, device=dev)
+plan = planmod.Plan.from_tensors(inc.N, ptr, ind)
+Y = torch.empty(inc.N, F, device=dev)
+ws = torch.empty(max(plan.workspace_bytes(F), 256), dtype=torch.uint8, device=dev)
+L = _lib.lib()
+buf = (ctypes.c_ulonglong * 8)()
+for _ in range(3):
+    plan.aggregate(ptr, ind, X, out=Y, workspace=ws, variant="fused")
+torch.cuda.synchronize()
+L.hg_debug_read_stamps(buf, 1)
+n = 10
+for _ in range(n):
+    plan.aggregate(ptr, ind, X, out=Y, workspace=ws, variant="fused")
+torch.cuda.synchronize()
+L.hg_debug_read_stamps(buf, 1)
+names = ["descriptor", "issue+wait lists", "barrier 1", "hop 1 (gather+tile)", "barrier 2", "hop 2 (tile->Y)"]
+tot = sum(buf[i] for i in range(6))
+info = plan.prepare(F)
+waves = info["panels"] * 4 * n
+for i, nm in enumerate(names):
+    print("%-22s %6.1f %%   %8.0f cycles/wave" % (nm, 100.0 * buf[i] / tot, buf[i] / waves))
+print("total cycles/wave %.0f" % (tot / waves))
