@@ -679,6 +679,213 @@ __global__ __launch_bounds__(256) void fused_persist_kernel(const FusedArgs a) {
   }
 }
 
+// Wave-specialised persistent form: 4 compute waves + 1 loader wave per
+// workgroup, two list buffers in LDS.  While the compute waves gather and sum
+// panel i, the loader wave copies the lists of panel i+1 into the other buffer by
+// LDS-DMA (global_load_lds, no registers) and gathers its scales.  The loader's
+// memory counter is its own, so -- unlike a register prefetch issued by the
+// compute waves, whose row gathers would queue behind it -- the descriptor ->
+// lists latency is entirely off the compute waves' critical path.
+struct WsLists {
+  int32_t *soff;   // [cap + 1]
+  float *sA, *sB;  // [cap]
+  int32_t *seid;   // [cap]
+  int32_t *spm;    // [mem_cap]
+  int32_t *sptr;   // [rows_cap + 1]
+  float *sdeg;     // [rows_cap]
+  int32_t *srow;   // [rows_cap]
+  uint16_t *svs;   // [vslot_cap]
+  int32_t *hdr;    // [4]: nslots, nrows
+};
+
+__device__ __forceinline__ size_t ws_lists_dwords(const FusedArgs &a) {
+  return (size_t)(a.cap + 1) + 3 * (size_t)a.cap + a.mem_cap + (a.rows_cap + 1) + 2 * (size_t)a.rows_cap +
+         (a.vslot_cap + 1) / 2 + 4;
+}
+
+__device__ __forceinline__ WsLists ws_carve(int32_t *p, const FusedArgs &a) {
+  WsLists L;
+  L.soff = p;
+  L.sA = reinterpret_cast<float *>(L.soff + a.cap + 1);
+  L.sB = L.sA + a.cap;
+  L.seid = reinterpret_cast<int32_t *>(L.sB + a.cap);
+  L.spm = L.seid + a.cap;
+  L.sptr = L.spm + a.mem_cap;
+  L.sdeg = reinterpret_cast<float *>(L.sptr + a.rows_cap + 1);
+  L.srow = reinterpret_cast<int32_t *>(L.sdeg + a.rows_cap);
+  L.hdr = L.srow + a.rows_cap;
+  L.svs = reinterpret_cast<uint16_t *>(L.hdr + 4);
+  return L;
+}
+
+// one wave copies n dwords global -> LDS with global_load_lds (64 dwords per instruction)
+__device__ __forceinline__ void dma_copy_dwords(const int32_t *src, int32_t *dst, int n, int lane) {
+  for (int i0 = 0; i0 < n; i0 += 64) {
+    if (i0 + lane < n)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i0 + lane),
+                                       (__attribute__((address_space(3))) void *)(dst + i0), 4, 0, 0);
+  }
+}
+__device__ __forceinline__ void dma_copy_u16(const uint16_t *src, uint16_t *dst, int n, int lane) {
+  for (int i0 = 0; i0 < n; i0 += 64) {
+    if (i0 + lane < n)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i0 + lane),
+                                       (__attribute__((address_space(3))) void *)(dst + i0), 2, 0, 0);
+  }
+}
+
+template <int LPR, int VEC, int U>
+__global__ __launch_bounds__(320) void fused_ws_kernel(const FusedArgs a) {
+  constexpr int CT = 256;  // compute threads
+  constexpr int NG = CT / LPR;
+  constexpr int TW = LPR * VEC;
+  using V = Vec<VEC>;
+  extern __shared__ int32_t smem[];
+  const int tid = threadIdx.x;
+  const bool loader = tid >= CT;
+  const int64_t F = a.F;
+
+  int first, step, last;
+  {
+    const int w = blockIdx.x, G = gridDim.x;
+    if (a.xcd_remap && G >= 8) {
+      const int x = w & 7, j = w >> 3;
+      const int J = (G - x + 7) >> 3;
+      const int cpx = a.npanels >> 3, rem = a.npanels & 7;
+      const int start = x * cpx + (x < rem ? x : rem);
+      first = start + j;
+      step = J;
+      last = start + cpx + (x < rem ? 1 : 0);
+    } else {
+      first = w;
+      step = G;
+      last = a.npanels;
+    }
+  }
+  if (first >= last) return;
+
+  float *tile = reinterpret_cast<float *>(smem);  // [cap * TW]
+  const size_t ldw = ws_lists_dwords(a);
+  const WsLists B0 = ws_carve(smem + a.cap * TW, a);
+  const WsLists B1 = ws_carve(smem + a.cap * TW + ldw, a);
+  const bool weighted = a.degE || a.W || a.degV;
+
+  // loader wave: bring panel `idx` into buffer L
+  auto load_panel = [&](int idx, const WsLists &L, int lane) {
+    const FPanel pn = a.panels[idx];
+    dma_copy_dwords(a.soff + pn.sbase, L.soff, pn.nslots + 1, lane);
+    dma_copy_dwords(a.pmem + pn.pm0, L.spm, pn.npm, lane);
+    dma_copy_dwords(a.pend + pn.r0, L.sptr + 1, pn.nrows, lane);
+    dma_copy_dwords(a.prow + pn.r0, L.srow, pn.nrows, lane);
+    dma_copy_u16(a.pvs + pn.v0, L.svs, pn.nvs, lane);
+    if (a.degE || a.W) dma_copy_dwords(a.slot_eid + pn.eid0, L.seid, pn.nslots, lane);
+    if (lane == 0) {
+      L.sptr[0] = 0;
+      L.hdr[0] = pn.nslots;
+      L.hdr[1] = pn.nrows;
+    }
+    return pn;
+  };
+  // second level (needs the ids that just landed)
+  auto load_scales = [&](const FPanel &pn, const WsLists &L, int lane) {
+    if (a.degE || a.W)
+      for (int i = lane; i < pn.nslots; i += 64) {
+        const int e = L.seid[i];  // -1: materialised row, already scaled
+        L.sA[i] = (a.degE && e >= 0) ? a.degE[e] : 1.f;
+        L.sB[i] = (a.W && e >= 0) ? a.W[e] : 1.f;
+      }
+    if (a.degV)
+      for (int i = lane; i < pn.nrows; i += 64) L.sdeg[i] = a.degV[L.srow[i]];
+  };
+
+  if (loader) {
+    const int lane = tid - CT;
+    const FPanel pn = load_panel(first, B0, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (weighted) load_scales(pn, B0, lane);
+  }
+  __syncthreads();
+
+  int it = 0;
+  for (int cur = first; cur < last; cur += step, it++) {
+    const WsLists &L = (it & 1) ? B1 : B0;
+    const WsLists &Ln = (it & 1) ? B0 : B1;
+    const bool has_next = cur + step < last;
+    if (loader) {
+      const int lane = tid - CT;
+      FPanel pn{};
+      if (has_next) pn = load_panel(cur + step, Ln, lane);
+      __syncthreads();  // (M) do not hold the compute waves back
+      if (has_next) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (weighted) load_scales(pn, Ln, lane);
+      }
+      __syncthreads();  // (X) next buffer complete, this panel consumed
+      continue;
+    }
+    const int gl = tid & (LPR - 1);
+    const int lcol = gl * VEC;
+    const int col = blockIdx.y * TW + lcol;
+    const bool col_ok = col < a.F;
+    const int g = tid / LPR;
+    const int nslots = L.hdr[0], nrows = L.hdr[1];
+    {  // ---- hop 1: slots -> LDS tile
+      const int spg = (nslots + NG - 1) / NG;
+      int k = min(g * spg, nslots);
+      const int ke = min(k + spg, nslots);
+      if (k < ke) {
+        auto flush = [&](int slot, V acc) {
+          if (a.degE) acc.mul(L.sA[slot]);
+          if (a.W) acc.mul(L.sB[slot]);
+          acc.store(tile + slot * TW + lcol);
+        };
+        int pos = L.soff[k];
+        const int stop = L.soff[ke];
+        int slot_end = L.soff[k + 1];
+        V acc = V::zero();
+        while (pos < stop) {
+          const int n = min(U, stop - pos);
+          V v[U];
+#pragma unroll
+          for (int j = 0; j < U; j++) {
+            const int ent = L.spm[pos + min(j, n - 1)];
+            const float *base = ent < 0 ? a.Xe_mat : a.X;
+            const int64_t idx = ent & 0x7fffffff;
+            v[j] = col_ok ? V::load(base + idx * F + col) : V::zero();
+          }
+#pragma unroll
+          for (int j = 0; j < U; j++) {
+            if (j < n) {
+              while (slot_end <= pos + j) {
+                flush(k, acc);
+                acc = V::zero();
+                k++;
+                slot_end = L.soff[k + 1];
+              }
+              acc.add(v[j]);
+            }
+          }
+          pos += n;
+        }
+        flush(k, acc);
+      }
+    }
+    __syncthreads();  // (M)
+    {  // ---- hop 2: vertices <- LDS tile
+      const int rpg = (nrows + NG - 1) / NG;
+      const int r0 = min(g * rpg, nrows), r1 = min(r0 + rpg, nrows);
+      for (int r = r0; r < r1; r++) {
+        V acc = V::zero();
+        const int pb = L.sptr[r], pe = L.sptr[r + 1];
+        for (int p = pb; p < pe; p++) acc.add(V::load(tile + (int)L.svs[p] * TW + lcol));
+        if (a.degV && pe > pb) acc.mul(L.sdeg[r]);
+        if (col_ok) acc.store(a.Y + (int64_t)L.srow[r] * F + col);
+      }
+    }
+    __syncthreads();  // (X)
+  }
+}
+
 // The reference's register-fused scheme on wave64: LPR lanes = LPR feature
 // columns of one task, 64/LPR tasks per wave.  Gather-sum the read partition,
 // scale by degE*W, scatter acc*degV[v] to the write partition with hardware
@@ -728,7 +935,8 @@ struct Tuning {
   int fused_bs = 256;
   int fused_u = 4;
   int fused_dma = 0;
-  int fused_persist = 1;
+  int fused_persist = 0;
+  int fused_ws = 1;
   int fused_grid = 0;
   int fused_debug = 0;  // ablation bits for fused_panel_kernel (timing experiments only)
 };
@@ -742,6 +950,7 @@ static const Tuning &tuning() {
     if (const char *e = getenv("HG_FUSED_U")) x.fused_u = atoi(e);
     if (const char *e = getenv("HG_FUSED_DMA")) x.fused_dma = atoi(e) != 0;
     if (const char *e = getenv("HG_FUSED_PERSIST")) x.fused_persist = atoi(e) != 0;
+    if (const char *e = getenv("HG_FUSED_WS")) x.fused_ws = atoi(e) != 0;
     if (const char *e = getenv("HG_FUSED_GRID")) x.fused_grid = atoi(e);
     if (const char *e = getenv("HG_FUSED_DEBUG")) x.fused_debug = atoi(e);
     return x;
@@ -814,16 +1023,30 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
     hipLaunchKernelGGL((fused_dma_kernel<LPR, VEC>), grid, dim3(256), lds_dma, stream, a);
     return hipGetLastError();
   }
+  static int num_cu = 0;
+  if (num_cu == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || num_cu <= 0)
+      num_cu = 256;
+  }
+  if (t.fused_ws) {
+    // wave-specialised persistent kernel: 4 compute waves + 1 loader wave, two list buffers.
+    // Grid = workgroups resident at once, from the LDS footprint (the binding resource here);
+    // a larger grid would run a second, mostly idle round.
+    const size_t ldw = (size_t)(a.cap + 1) + 3 * (size_t)a.cap + a.mem_cap + (a.rows_cap + 1) +
+                       2 * (size_t)a.rows_cap + (a.vslot_cap + 1) / 2 + 4;
+    const size_t lds_ws = (size_t)a.cap * TW * 4 + 2 * ldw * 4 + 16;
+    int per_cu = (int)std::min<size_t>(6, (160 * 1024) / (lds_ws + 256));  // 6 x 5 waves <= 32 waves/CU
+    if (per_cu < 1) per_cu = 1;
+    const int want = t.fused_grid > 0 ? t.fused_grid : num_cu * per_cu;
+    const int nwg = std::min(a.npanels, want);
+    hipLaunchKernelGGL((fused_ws_kernel<LPR, VEC, 4>), dim3(nwg, col_tiles), dim3(320), lds_ws, stream, a);
+    return hipGetLastError();
+  }
   if (t.fused_persist && a.cap <= 256 && a.mem_cap <= 1024 && a.rows_cap <= 256 && a.vslot_cap <= 512) {
     // persistent grid: as many workgroups as the chip holds at once (an oversized grid
     // would only queue: workgroups never wait for each other)
-    static int num_cu = 0;
-    if (num_cu == 0) {
-      int dev = 0;
-      if (hipGetDevice(&dev) != hipSuccess ||
-          hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || num_cu <= 0)
-        num_cu = 256;
-    }
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_persist_kernel<LPR, VEC, 4>, 256, lds) !=
             hipSuccess || per_cu <= 0)
