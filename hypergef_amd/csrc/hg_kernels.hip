@@ -777,8 +777,9 @@ __global__ __launch_bounds__(320) void fused_ws_kernel(const FusedArgs a) {
     dma_copy_dwords(a.pmem + pn.pm0, L.spm, pn.npm, lane);
     dma_copy_dwords(a.pend + pn.r0, L.sptr + 1, pn.nrows, lane);
     dma_copy_dwords(a.prow + pn.r0, L.srow, pn.nrows, lane);
-    dma_copy_u16(a.pvs + pn.v0, L.svs, pn.nvs, lane);
     if (a.degE || a.W) dma_copy_dwords(a.slot_eid + pn.eid0, L.seid, pn.nslots, lane);
+    // 16-bit slot ids go through registers (sub-dword LDS-DMA is not relied upon)
+    for (int i = lane; i < pn.nvs; i += 64) L.svs[i] = a.pvs[pn.v0 + i];
     if (lane == 0) {
       L.sptr[0] = 0;
       L.hdr[0] = pn.nslots;
