@@ -849,10 +849,11 @@ __global__ __launch_bounds__(320) void fused_ws_kernel(const FusedArgs a) {
           V v[U];
 #pragma unroll
           for (int j = 0; j < U; j++) {
-            const int ent = L.spm[pos + min(j, n - 1)];
+            const bool on = col_ok && j < n;  // predicated off: no duplicate traffic
+            const int ent = on ? L.spm[pos + j] : 0;
             const float *base = ent < 0 ? a.Xe_mat : a.X;
             const int64_t idx = ent & 0x7fffffff;
-            v[j] = col_ok ? V::load(base + idx * F + col) : V::zero();
+            v[j] = on ? V::load(base + idx * F + col) : V::zero();
           }
 #pragma unroll
           for (int j = 0; j < U; j++) {
@@ -1042,7 +1043,12 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
     if (per_cu < 1) per_cu = 1;
     const int want = t.fused_grid > 0 ? t.fused_grid : num_cu * per_cu;
     const int nwg = std::min(a.npanels, want);
-    hipLaunchKernelGGL((fused_ws_kernel<LPR, VEC, 4>), dim3(nwg, col_tiles), dim3(320), lds_ws, stream, a);
+    if (t.fused_u == 16)
+      hipLaunchKernelGGL((fused_ws_kernel<LPR, VEC, 16>), dim3(nwg, col_tiles), dim3(320), lds_ws, stream, a);
+    else if (t.fused_u == 8)
+      hipLaunchKernelGGL((fused_ws_kernel<LPR, VEC, 8>), dim3(nwg, col_tiles), dim3(320), lds_ws, stream, a);
+    else
+      hipLaunchKernelGGL((fused_ws_kernel<LPR, VEC, 4>), dim3(nwg, col_tiles), dim3(320), lds_ws, stream, a);
     return hipGetLastError();
   }
   if (t.fused_persist && a.cap <= 256 && a.mem_cap <= 1024 && a.rows_cap <= 256 && a.vslot_cap <= 512) {
