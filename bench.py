@@ -194,7 +194,10 @@ def main():
 
     total_nnz = inc.nnz * world
     value = total_nnz * args.steps / wall
-    launches = 2 if args.variant in ("auto", "pull") else 1
+    resolved = plan.auto_variant(F) if args.variant == "auto" else args.variant
+    launches = 2 if resolved == "pull" else 1
+    dominant = {"pull": "gather_rows_kernel (hop 1 + hop 2 launches averaged)",
+                "fused": "fused_panel_kernel", "push_atomic": "push_groups_kernel"}[resolved]
     balg = b_alg(inc.N, inc.M, inc.nnz, F, n_w)
     kern_avg_s = dev_s / (args.steps * launches)
     achieved = balg / launches / kern_avg_s / 1e9
@@ -215,11 +218,11 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": wl_name, "op": "hgnnaggr" if args.weighted else "H*H^T*X (aggr_proto)",
                    "vertices_per_gpu": inc.N, "hyperedges_per_gpu": inc.M, "nnz_per_gpu": inc.nnz,
-                   "feat_len": F, "variant": args.variant,
+                   "feat_len": F, "variant": args.variant, "resolved_variant": resolved,
                    "sharding": "hyperedge groups (one hypergraph batch per rank), no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "gather_rows_kernel (hop 1 + hop 2 launches averaged)",
+                     "kernel": dominant,
                      "algorithmic_bytes_per_launch": balg / launches,
                      "avg_launch_us": kern_avg_s * 1e6, "launches_per_step": launches},
         "hbm_gbs_algorithmic": balg * world * args.steps / wall / 1e9,

@@ -187,6 +187,23 @@ Carve carve(const hg_plan *p, int32_t F) {
   return c;
 }
 
+// What HG_VARIANT_AUTO resolves to.  Fused pays when most of the incidence mass sits
+// in hyperedges small enough to be recomputed per panel (measured, profiles/: cora /
+// citeseer / pubmed shapes 1.05-1.4x over the two-phase pull) and loses when nearly
+// everything has to be materialised anyway (power-law hubs).  First a free test on
+// the size histogram, then the built schedule.
+int pick_variant(const hg_plan *plan, int32_t F, bool vec4, bool dma, int32_t *variant,
+                 const hg::FusedSched **f) {
+  *variant = HG_VARIANT_PULL;
+  if (plan->small_nnz_frac >= 0.5) {
+    int rc = get_fused(plan, F, vec4, dma, f);
+    if (rc != HG_OK) return rc;
+    if ((*f)->pmem_entries <= (int64_t)(2.6 * (double)plan->nnz) && (int64_t)(*f)->n_mat * 4 <= plan->M)
+      *variant = HG_VARIANT_FUSED;
+  }
+  return HG_OK;
+}
+
 int run_sched(const hg_plan *p, const hg::Sched &s, int32_t F, const int32_t *ptr,
               const int32_t *ind, const float *src, const float *scaleA, const float *scaleB,
               const int32_t *scale_map, const int32_t *dst_map, float *dst, float *partial,
@@ -279,6 +296,12 @@ int plan_build(hg_plan **out, int32_t N, int32_t M, const int32_t *csrptr_t,
     hg::transpose_csr(M, N, csrptr_t, colind_t, p->ptr_v, p->ind_v);
     hg::build_sched(M, csrptr_t, o, p->sched[0]);
     hg::build_sched(N, p->ptr_v.data(), o, p->sched[1]);
+    int64_t small = 0;
+    for (int32_t e = 0; e < M; e++) {
+      const int32_t len = csrptr_t[e + 1] - csrptr_t[e];
+      if (len <= o.t_big) small += len;
+    }
+    p->small_nnz_frac = p->nnz > 0 ? (double)small / (double)p->nnz : 0.0;
   } catch (const std::bad_alloc &) {
     delete p;
     hg::set_error("hg_plan_create: host allocation failed");
@@ -402,6 +425,17 @@ int hg_plan_get_schedule(const hg_plan *p, int32_t hop, int32_t *panels, int32_t
   return HG_OK;
 }
 
+int hg_plan_auto_variant(const hg_plan *p, int32_t F) {
+  if (!p || F <= 0) {
+    hg::set_error("hg_plan_auto_variant: bad argument");
+    return HG_ERR_INVALID;
+  }
+  int32_t variant = HG_VARIANT_PULL;
+  const hg::FusedSched *f = nullptr;
+  int rc = pick_variant(p, F, F % 4 == 0, hg::fused_use_dma(), &variant, &f);
+  return rc != HG_OK ? rc : variant;
+}
+
 int hg_plan_prepare(const hg_plan *p, int32_t F, hg_fused_info *info) {
   if (!p || F <= 0) {
     hg::set_error("hg_plan_prepare: bad argument");
@@ -515,11 +549,14 @@ int hg_aggr_fused_f32(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
   const Carve c = carve(plan, F);
   char *ws = static_cast<char *>(workspace);
   float *Xe = reinterpret_cast<float *>(ws + c.xe);
+  const bool vec4 = (F % 4 == 0) && aligned16(X) && aligned16(Y) && aligned16(Xe);
+  const bool dma = hg::fused_use_dma();
+  const hg::FusedSched *f = nullptr;
+  if (variant == HG_VARIANT_AUTO) {
+    if ((rc = pick_variant(plan, F, vec4, dma, &variant, &f)) != HG_OK) return rc;
+  }
   if (variant == HG_VARIANT_FUSED) {
-    const bool vec4 = (F % 4 == 0) && aligned16(X) && aligned16(Y) && aligned16(Xe);
-    const hg::FusedSched *f = nullptr;
-    const bool dma = hg::fused_use_dma();
-    if ((rc = get_fused(plan, F, vec4, dma, &f)) != HG_OK) return rc;
+    if (!f && (rc = get_fused(plan, F, vec4, dma, &f)) != HG_OK) return rc;
     // (a) materialised hyperedges (long ones, and those of hub vertices): Xe_mat rows
     if (f->n_mat > 0) {
       rc = run_sched(plan, f->mat_sched, F, f->d_mat_ptr, f->d_mat_ind, X, degE, W, f->d_mat_eid,

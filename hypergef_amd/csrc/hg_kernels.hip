@@ -938,7 +938,7 @@ struct Tuning {
   int fused_u = 4;
   int fused_dma = 0;
   int fused_persist = 0;
-  int fused_ws = 1;
+  int fused_ws = 0;
   int fused_grid = 0;
   int fused_debug = 0;  // ablation bits for fused_panel_kernel (timing experiments only)
 };

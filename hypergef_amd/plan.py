@@ -108,6 +108,13 @@ class Plan:
         _lib.check(_lib.lib().hg_plan_prepare(self._h, F, ctypes.byref(info)))
         return info.as_dict()
 
+    def auto_variant(self, F):
+        """Name of the kernel family `variant="auto"` runs for feature width F."""
+        v = _lib.lib().hg_plan_auto_variant(self._h, F)
+        if v < 0:
+            _lib.check(v)
+        return {code: name for name, code in _lib.VARIANTS.items()}[v]
+
     def workspace_bytes(self, F):
         return int(_lib.lib().hg_plan_workspace_bytes(self._h, F))
 

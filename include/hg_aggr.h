@@ -152,6 +152,9 @@ HG_API int hg_plan_get_vertex_csr_device(const hg_plan *plan, const int32_t **pt
  * this itself on first use of a width, but that first call allocates device
  * memory and so cannot be captured into a hipGraph.  info may be NULL. */
 HG_API int hg_plan_prepare(const hg_plan *plan, int32_t F, hg_fused_info *info);
+/* The variant HG_VARIANT_AUTO resolves to for feature width F (builds the
+ * F-dependent schedule if the choice needs it); negative hg_status on error. */
+HG_API int hg_plan_auto_variant(const hg_plan *plan, int32_t F);
 /* Host copy of one hop's schedule as int32 quadruples (tests, tools): panels
  * {row0, nrows, nnz0, nnz_cnt}, tasks {row, beg, end, slot}, fixups {row,
  * first_slot, count, 0}; sizes from hg_plan_get_info.  Pointers may be NULL. */
