@@ -22,7 +22,7 @@ VARIANTS = {"auto": HG_VARIANT_AUTO, "pull": HG_VARIANT_PULL, "push_atomic": HG_
 
 # every symbol include/hg_aggr.h declares (tests check the library exports all)
 SYMBOLS = (
-    "hg_version", "hg_last_error", "hg_status_string", "hg_balance_schedule",
+    "hg_version", "hg_last_error", "hg_status_string", "hg_balance_schedule", "hg_mtx_read", "hg_free",
     "hg_plan_create_host", "hg_plan_create_device", "hg_plan_destroy", "hg_plan_get_info",
     "hg_plan_get_vertex_csr", "hg_plan_get_vertex_csr_device", "hg_plan_get_schedule", "hg_plan_prepare", "hg_plan_auto_variant",
     "hg_plan_workspace_bytes",
@@ -90,6 +90,12 @@ def lib():
     L.hg_balance_schedule.restype = ctypes.c_int
     L.hg_balance_schedule.argtypes = [i32, i32, vp, ctypes.POINTER(i64), ctypes.POINTER(i64),
                                       vp, vp, vp, vp]
+    L.hg_mtx_read.restype = ctypes.c_int
+    L.hg_mtx_read.argtypes = [ctypes.c_char_p, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i64),
+                              ctypes.POINTER(ctypes.POINTER(i32)), ctypes.POINTER(ctypes.POINTER(i32)),
+                              ctypes.POINTER(ctypes.POINTER(i32)), ctypes.POINTER(ctypes.POINTER(i32))]
+    L.hg_free.restype = None
+    L.hg_free.argtypes = [vp]
     L.hg_plan_create_host.restype = ctypes.c_int
     L.hg_plan_create_host.argtypes = [ctypes.POINTER(vp), i32, i32, vp, vp, ctypes.POINTER(PlanOpts)]
     L.hg_plan_create_device.restype = ctypes.c_int

@@ -122,6 +122,17 @@ HG_API int hg_balance_schedule(int32_t nrow, int32_t ngs, const int32_t *csrptr_
                         int64_t *n_key, int64_t *n_group, int32_t *key,
                         int32_t *row, int32_t *group_st, int32_t *group_ed);
 
+/* ---- input format ----------------------------------------------------------
+ * MatrixMarket reader with the semantics of the reference's DataLoader
+ * (include/dataloader/dataloader.hpp:22-180): 1-based `row col [value]` lines,
+ * values dropped, entries sorted by (row, col); `symmetric` files are mirrored
+ * and de-duplicated, `general` files keep duplicates.  Returns H (rows =
+ * vertices) in CSR and its stable transpose H_T (rows = hyperedges, members
+ * ascending).  The four arrays are malloc'ed; release each with hg_free. */
+HG_API int hg_mtx_read(const char *path, int32_t *nrow, int32_t *ncol, int64_t *nnz,
+                       int32_t **H_ptr, int32_t **H_ind, int32_t **HT_ptr, int32_t **HT_ind);
+HG_API void hg_free(void *p);
+
 /* ---- plan ------------------------------------------------------------------
  * The plan is this backend's own schedule (what hgnn_balancer,
  * include/taskbalancer/balancer.cuh:189-275, is to the reference kernels): it

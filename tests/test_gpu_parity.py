@@ -300,3 +300,25 @@ def test_fused_variant_schedules(hg, oracle, shape, opts):
         assert info["panels"] > 0 or info["n_hub"] == inc.N
         Y = plan.aggregate(ptr, ind, _dev(X), _dev(degE.ravel()), _dev(degV.ravel()), _dev(W), variant="fused")
         _assert_close(Y, ref)
+
+
+def test_aggr_proto_cli_gpu(hg, tmp_path):
+    """The reference CLI's flow on the GPU: every variant validates against the host path."""
+    import os, subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "bin", "aggr_proto")
+    assert os.path.exists(exe), "bin/aggr_proto missing: run __graft_entry__.build()"
+    for shape, F in (("citeseer", 32), ("pubmed", 64)):
+        inc = _make(shape)
+        mtx = tmp_path / (shape + ".mtx")
+        synth.write_mtx(str(mtx), inc)
+        r = subprocess.run([exe, str(mtx), str(F), "--iter", "10"], capture_output=True, text=True, cwd=tmp_path)
+        assert r.returncode == 0, r.stdout + r.stderr
+        out = r.stdout
+        assert "check failed!" not in out and "Wrong result" not in out
+        assert out.count("check passed!") == 4  # rocSPARSE two-step, edge-fused, pull, fused
+        for needle in ("The time of two rocsparse spmm", "test time one baseline fused kernel:",
+                       "test ef full tune time one", "test ef shm tune time one", "within 1e-5"):
+            assert needle in out, out
+    rows = (tmp_path / "result.csv").read_text().strip().splitlines()
+    assert len(rows) == 2 and all(len(r.rstrip(",").split(",")) >= 9 for r in rows)

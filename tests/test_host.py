@@ -181,3 +181,56 @@ def test_ops_refuse_cpu_tensors(hg):
     ptr, ind = torch.from_numpy(inc.csrptr), torch.from_numpy(inc.colind)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         hg.ops.unignnaggr(ptr, ptr, ptr, ptr, ptr, ind, x)
+
+
+def test_native_mtx_reader_matches_oracle(hg, oracle, tmp_path):
+    """hg_mtx_read vs the oracle's restatement of dataloader.hpp:22-141."""
+    from hypergef_amd.mtx import read_mtx
+    cases = {
+        "general_dupes.mtx": "%%MatrixMarket matrix coordinate real general\n% c\n3 4 5\n"
+                             "3 1 1.0\n1 2 1.0\n1 1 1.0\n2 4 1.0\n1 2 1.0\n",
+        "symmetric.mtx": "%%MatrixMarket matrix coordinate pattern symmetric\n3 3 3\n2 1\n3 3\n2 1\n",
+        "integer.mtx": "%%MatrixMarket matrix coordinate integer general\n2 2 2\n2 2 7\n1 1 3\n",
+    }
+    for fname, text in cases.items():
+        p = tmp_path / fname
+        p.write_text(text)
+        inc, (H_ptr, H_ind) = read_mtx(p)
+        nrow, ncol, o_ptr, o_ind = oracle.read_mtx(str(p))
+        assert (inc.N, inc.M) == (nrow, ncol)
+        assert np.array_equal(H_ptr, o_ptr) and np.array_equal(H_ind, o_ind)
+        t_ptr, t_ind = oracle.transpose_csr(nrow, ncol, o_ptr, o_ind)
+        assert np.array_equal(inc.csrptr, t_ptr) and np.array_equal(inc.colind, t_ind)
+    src = synth.pubmed_shape()
+    q = tmp_path / "pubmed.mtx"
+    synth.write_mtx(str(q), src)
+    inc, _ = read_mtx(q)
+    assert np.array_equal(inc.csrptr, src.csrptr) and np.array_equal(inc.colind, src.colind)
+    from hypergef_amd import _lib
+    with pytest.raises(_lib.HgError, match="not found"):
+        read_mtx(tmp_path / "missing.mtx")
+    bad = tmp_path / "bad.mtx"
+    bad.write_text("%%MatrixMarket matrix coordinate real general\n2 2 3\n1 1 1.0\n")
+    with pytest.raises(_lib.HgError, match="not enough rows"):
+        read_mtx(bad)
+
+
+def test_aggr_proto_cli_cpu_mode(hg, tmp_path):
+    """BASELINE.json configs[0]: `aggr_proto <mtx> 32` plumbing on the CPU path, no GPU."""
+    import subprocess
+    exe = os.path.join(ROOT, "bin", "aggr_proto")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "hypergef_amd", "csrc"), "cli"], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 1 and r.stdout.startswith("Input: first get the path of sparse matrix")
+    mtx = tmp_path / "cora.mtx"
+    inc = synth.cora_shape()
+    synth.write_mtx(str(mtx), inc)
+    r = subprocess.run([exe, str(mtx), "32", "--cpu"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    assert lines[0] == "H.nrow %d H.ncol %d H_nnz %d" % (inc.N, inc.M, inc.nnz)
+    assert "bitwise equal" in lines[1]
+    assert "start spmm test" in lines and "start fused kernel test" in lines and lines.count("check passed!") == 2
+    row = (tmp_path / "result.csv").read_text().strip().split(",")
+    assert row[0] == str(mtx) and row[1] == "32" and len(row) == 10
