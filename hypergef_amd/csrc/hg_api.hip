@@ -523,6 +523,32 @@ int hg_aggr_push_groups_f32(int32_t N, int32_t M, int32_t F, int64_t n_group,
   return HG_OK;
 }
 
+int hg_gather_max_f32(int32_t M, int32_t F, const int32_t *csrptr_t, const int32_t *colind_t,
+                      const float *X, const float *degE, const float *W, float *Xe, int32_t *record,
+                      hg_stream_t stream) {
+  if (M < 0 || F <= 0 || !csrptr_t || !X || !Xe || !record || (int64_t)M * F >= ((int64_t)1 << 39)) {
+    hg::set_error("hg_gather_max_f32: bad argument");
+    return HG_ERR_INVALID;
+  }
+  hipError_t e = hg::launch_gather_max(M, F, csrptr_t, colind_t, X, degE, W, Xe, record,
+                                       static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return hip_fail("gather_max launch", e);
+  return HG_OK;
+}
+
+int hg_scatter_record_f32(int32_t N, int32_t M, int32_t F, const float *T, const int32_t *record,
+                          const float *degV, float *Y, hg_stream_t stream) {
+  if (N < 0 || M < 0 || F <= 0 || !T || !record || !Y) {
+    hg::set_error("hg_scatter_record_f32: bad argument");
+    return HG_ERR_INVALID;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  HG_HIP(hipMemsetAsync(Y, 0, (size_t)N * F * sizeof(float), s));
+  hipError_t e = hg::launch_scatter_record(M, F, T, record, degV, Y, s);
+  if (e != hipSuccess) return hip_fail("scatter_record launch", e);
+  return HG_OK;
+}
+
 int hg_aggr_fused_f32(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
                       const int32_t *colind_t, const float *X, const float *degE,
                       const float *degV, const float *W, float *Y, void *workspace,

@@ -57,5 +57,10 @@ int fused_tile_row_floats(int F, bool vec4);
 bool fused_use_dma();
 hipError_t read_stamps(unsigned long long *out, bool reset);
 hipError_t launch_push(const PushArgs &a, hipStream_t stream);
+hipError_t launch_gather_max(int32_t M, int32_t F, const int32_t *ptr, const int32_t *ind, const float *X,
+                             const float *degE, const float *W, float *Xe, int32_t *record,
+                             hipStream_t stream);
+hipError_t launch_scatter_record(int32_t M, int32_t F, const float *T, const int32_t *record,
+                                 const float *degV, float *Y, hipStream_t stream);
 
 }  // namespace hg

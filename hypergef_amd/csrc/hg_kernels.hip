@@ -1133,4 +1133,63 @@ hipError_t launch_push(const PushArgs &a, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// first_aggr = max (HGNNAggr_f1max_forward_kernel, hgnnaggr_cuda.cu:144-177): per
+// hyperedge and feature column the running maximum starts at -1e5, a member
+// replaces it on strict >, the winning vertex id goes to record[e, k] (0 when no
+// member beats -1e5), then Xe = max * (degE * W).  One lane per (hyperedge,
+// column); the second hop is the ordinary row gather over H.
+__global__ __launch_bounds__(256) void gather_max_kernel(int32_t M, int32_t F, const int32_t *ptr,
+                                                         const int32_t *ind, const float *X,
+                                                         const float *degE, const float *W, float *Xe,
+                                                         int32_t *record) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (int64_t)M * F) return;
+  const int32_t e = (int32_t)(t / F), k = (int32_t)(t % F);
+  float best = -1e5f;
+  int32_t who = 0;
+  for (int32_t p = ptr[e]; p < ptr[e + 1]; p++) {
+    const int32_t u = ind[p];
+    const float x = X[(int64_t)u * F + k];
+    if (x > best) {
+      best = x;
+      who = u;
+    }
+  }
+  const float degE_val = degE ? degE[e] : 1.f, W_val = W ? W[e] : 1.f;
+  best *= degE_val * W_val;
+  Xe[t] = best;
+  record[t] = who;
+}
+
+// Backward of first_aggr = max (HGNNAggr_f1max_backward_kernel, hgnnaggr_cuda.cu:179-208):
+// Y[record[e,k], k] += T[e,k] * degV[record[e,k]], T = the scaled hyperedge sums of grad.
+__global__ __launch_bounds__(256) void scatter_record_kernel(int32_t M, int32_t F, const float *T,
+                                                             const int32_t *record, const float *degV,
+                                                             float *Y) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (int64_t)M * F) return;
+  const int32_t k = (int32_t)(t % F);
+  const int64_t v = record[t];
+  atomicAdd(Y + v * F + k, T[t] * (degV ? degV[v] : 1.f));
+}
+
+hipError_t launch_gather_max(int32_t M, int32_t F, const int32_t *ptr, const int32_t *ind, const float *X,
+                             const float *degE, const float *W, float *Xe, int32_t *record,
+                             hipStream_t stream) {
+  const int64_t n = (int64_t)M * F;
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(gather_max_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, M, F, ptr, ind,
+                     X, degE, W, Xe, record);
+  return hipGetLastError();
+}
+
+hipError_t launch_scatter_record(int32_t M, int32_t F, const float *T, const int32_t *record,
+                                 const float *degV, float *Y, hipStream_t stream) {
+  const int64_t n = (int64_t)M * F;
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(scatter_record_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, M, F, T,
+                     record, degV, Y);
+  return hipGetLastError();
+}
+
 }  // namespace hg

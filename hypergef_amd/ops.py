@@ -111,14 +111,81 @@ def hgnnaggr(balan_key, balan_row, group_st, group_ed, csrptr_t, indices_t, node
                           degE, degV, W)
 
 
+def _edge_sizes(csrptr_t):
+    return (csrptr_t[1:] - csrptr_t[:-1]).to(torch.float32)
+
+
+class _MeanF1(torch.autograd.Function):
+    """first hop = mean (HGNNAggr_MeanF1, hgnnaggr.cc:66-90; kernels hgnnaggr_cuda.cu:86-142):
+    the hyperedge sum is scaled by degE*W/|e| (one factor, as the reference computes it), the
+    second hop is the ordinary one.  Backward = the same operator on grad_out (the reference's
+    backward kernel differs only in where it divides by |e|)."""
+
+    @staticmethod
+    def forward(ctx, csrptr_t, indices_t, node_feat, degE, degV, W):
+        _check_index(csrptr_t, "csrptr_t")
+        s = _flat(degE) * _flat(W) / _edge_sizes(csrptr_t)
+        s = torch.where(torch.isfinite(s), s, torch.zeros_like(s))  # empty hyperedge: never read
+        ctx.saved = (csrptr_t, indices_t, s, _flat(degV))
+        plan = cached_plan(node_feat.shape[0], csrptr_t, indices_t)
+        return plan.aggregate(csrptr_t, indices_t, node_feat, s, _flat(degV), None)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        csrptr_t, indices_t, s, degV = ctx.saved
+        plan = cached_plan(grad_out.shape[0], csrptr_t, indices_t)
+        g = plan.aggregate(csrptr_t, indices_t, grad_out.contiguous(), s, degV, None)
+        return None, None, g, None, None, None
+
+
+class _MaxF1(torch.autograd.Function):
+    """first hop = per-column max with arg-max table (HGNNAggr_MaxF1, hgnnaggr.cc:92-120;
+    kernels hgnnaggr_cuda.cu:144-208).  Loop bounds use M, not the reference's N (defect D2)."""
+
+    @staticmethod
+    def forward(ctx, csrptr_t, indices_t, node_feat, degE, degV, W):
+        _check_feat(node_feat, "node_feat")
+        _check_index(csrptr_t, "csrptr_t")
+        _check_index(indices_t, "indices_t")
+        N, F = node_feat.shape
+        M = csrptr_t.numel() - 1
+        degE, degV, W = _flat(degE), _flat(degV), _flat(W)
+        dev = node_feat.device
+        Xe = torch.empty((M, F), dtype=torch.float32, device=dev)
+        record = torch.empty((M, F), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().hg_gather_max_f32(M, F, _ptr(csrptr_t), _ptr(indices_t), _ptr(node_feat),
+                                                    _ptr(degE), _ptr(W), _ptr(Xe), _ptr(record),
+                                                    _stream_handle(dev)))
+        plan = cached_plan(N, csrptr_t, indices_t)
+        out = plan.gather_rows(1, csrptr_t, indices_t, Xe, degV, None)
+        ctx.saved = (csrptr_t, indices_t, degE, degV, W, record)
+        ctx.mark_non_differentiable(record)
+        return out, record
+
+    @staticmethod
+    def backward(ctx, grad_out, _grad_record):
+        csrptr_t, indices_t, degE, degV, W, record = ctx.saved
+        grad_out = grad_out.contiguous()
+        N, F = grad_out.shape
+        M = csrptr_t.numel() - 1
+        plan = cached_plan(N, csrptr_t, indices_t)
+        T = plan.gather_rows(0, csrptr_t, indices_t, grad_out, degE, W)  # (sum grad) * degE * W
+        g = torch.empty((N, F), dtype=torch.float32, device=grad_out.device)
+        with torch.cuda.device(grad_out.device):
+            _lib.check(_lib.lib().hg_scatter_record_f32(N, M, F, _ptr(T), _ptr(record), _ptr(degV), _ptr(g),
+                                                        _stream_handle(grad_out.device)))
+        return None, None, g, None, None, None
+
+
 def hgnnaggr_mean(csrptr_t, indices_t, node_feat, degE, degV, W):
     """hgnnaggr with f1 mean (hgnnaggr.cc:131-136)."""
-    raise NotImplementedError("first_aggr='mean' is not built yet (SURVEY.md 8(f) item 4)")
+    return _MeanF1.apply(csrptr_t, indices_t, node_feat, degE, degV, W)
 
 
 def hgnnaggr_max(csrptr_t, indices_t, node_feat, degE, degV, W):
-    """hgnnaggr with f1 max (hgnnaggr.cc:138-144)."""
-    raise NotImplementedError("first_aggr='max' is not built yet (SURVEY.md 8(f) item 4)")
+    """hgnnaggr with f1 max (hgnnaggr.cc:138-144): returns [out, record_table]."""
+    return list(_MaxF1.apply(csrptr_t, indices_t, node_feat, degE, degV, W))
 
 
 # ---- module `unignnaggr` (unignnaggr.cc:81-102) ------------------------------

@@ -209,6 +209,17 @@ HG_API int hg_gather_rows_f32(const hg_plan *plan, int32_t hop, int32_t F,
                        const float *scaleB, float *dst, void *workspace,
                        size_t workspace_bytes, hg_stream_t stream);
 
+/* first_aggr = "max" pieces (hgnnaggr_max, source/hgnnaggr/hgnnaggr_cuda.cu:144-208).
+ * hg_gather_max_f32: Xe[e,k] = (max_{u in e} X[u,k], start -1e5, strict >) * (degE[e]*W[e]),
+ * record[e,k] = winning vertex (0 if none).  The second hop is hg_gather_rows_f32(hop = 1).
+ * hg_scatter_record_f32 (backward): Y = 0; Y[record[e,k], k] += T[e,k] * degV[record[e,k]]. */
+HG_API int hg_gather_max_f32(int32_t M, int32_t F, const int32_t *csrptr_t, const int32_t *colind_t,
+                             const float *X, const float *degE, const float *W, float *Xe,
+                             int32_t *record, hg_stream_t stream);
+HG_API int hg_scatter_record_f32(int32_t N, int32_t M, int32_t F, const float *T,
+                                 const int32_t *record, const float *degV, float *Y,
+                                 hg_stream_t stream);
+
 /* The reference's kernel driven by the reference's schedule tensors
  * (HGNNAggr_forward_kernel(+_sf), hgnnaggr_cuda.cu:14-84; unweighted twins
  * hgnnAgg.cuh:33-53, 98-167): task g reads partition group_st[g] and scatters

@@ -322,3 +322,41 @@ def test_aggr_proto_cli_gpu(hg, tmp_path):
             assert needle in out, out
     rows = (tmp_path / "result.csv").read_text().strip().splitlines()
     assert len(rows) == 2 and all(len(r.rstrip(",").split(",")) >= 9 for r in rows)
+
+
+@pytest.mark.parametrize("shape", ["cora", "pubmed", "ragged"])
+def test_first_aggr_mean_and_max(hg, oracle, shape):
+    """hgnnaggr_mean / hgnnaggr_max (hgnnaggr.cc:131-144) vs the oracle's restatement of
+    hgnnaggr_cuda.cu:86-177 (loop bound fixed to M, defect D2)."""
+    inc = _make(shape)
+    F = 8
+    X, degE, degV, W, H_ptr, H_ind = _inputs(inc, F, oracle, seed=11, normal=True)
+    degE = np.where(np.isinf(degE), 0, degE).astype(np.float32)
+    ptr, ind = _dev(inc.csrptr), _dev(inc.colind)
+    ref_mean = oracle.hgnn_mean(inc.N, inc.M, F, inc.csrptr, inc.colind, X, degE, degV, W)
+    ref_max, ref_rec = oracle.hgnn_max(inc.N, inc.M, F, inc.csrptr, inc.colind, X, degE, degV, W)
+    x = _dev(X).requires_grad_(True)
+    y = hg.ops.hgnnaggr_mean(ptr, ind, x, _dev(degE), _dev(degV), _dev(W))
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref_mean, rtol=1e-5, atol=1e-6)
+    g = torch.ones_like(y)
+    y.backward(g)
+    ref_bwd = oracle.hgnn_mean(inc.N, inc.M, F, inc.csrptr, inc.colind, np.ones((inc.N, F), np.float32),
+                               degE, degV, W)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), ref_bwd, rtol=1e-5, atol=1e-6)
+
+    x2 = _dev(X).requires_grad_(True)
+    out, rec = hg.ops.hgnnaggr_max(ptr, ind, x2, _dev(degE), _dev(degV), _dev(W))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref_max, rtol=1e-5, atol=1e-6)
+    assert rec.dtype == torch.int32 and np.array_equal(rec.cpu().numpy(), ref_rec)
+    gm = torch.from_numpy(np.random.default_rng(5).standard_normal((inc.N, F)).astype(np.float32)).to(DEV)
+    out.backward(gm)
+    # reference backward (hgnnaggr_cuda.cu:179-208): scatter (sum grad)*degE*W*degV[rec] to rec only
+    gnp = gm.cpu().numpy().astype(np.float64)
+    exp = np.zeros((inc.N, F))
+    for e in range(inc.M):
+        mem = inc.colind[inc.csrptr[e]:inc.csrptr[e + 1]]
+        t = gnp[mem].sum(0) * float(degE[e, 0]) * float(W[e])
+        for k in range(F):
+            v = ref_rec[e, k]
+            exp[v, k] += t[k] * float(degV[v, 0])
+    np.testing.assert_allclose(x2.grad.cpu().numpy(), exp, rtol=2e-4, atol=2e-5)
