@@ -1,0 +1,184 @@
+"""The reference's hgsys-backend models on this backend.
+
+Mirrors HyperGsys/model/ugsys/{hgnn,unigin,unigcnii}.py and the wrappers
+HGsysHGNN / UniGCNII of HyperGsys/model/gnn.py:110-208 (same constructor
+arguments, same forward).  Reference defect D5 is fixed where it would crash:
+`HyperGsysUniGCNII.forward` uses its `alpha` / `beta` arguments (the reference
+reads unset attributes), and `UniGCNII` builds its hgsys layers for
+backend 'hgsys' as well as 'ugsys'.
+
+`backend="torch"` builds the same networks on plain `index_add_` (the PyG
+formulation, HyperGsys/model/pygnn/hgnn.py:25-38) -- the stand-in for the
+PyG / DGL baselines, which cannot be installed offline.  It runs on CPU or GPU.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .ops import HGNNAggr, UniGNNConv, UniGNNConvdeg
+
+
+# ---- hgsys convolutions (model/ugsys/*.py) -----------------------------------
+
+class HyperGsysHGNN(nn.Module):
+    def __init__(self, hyperg, in_channels, out_channels, first_aggr, heads=1):
+        super().__init__()
+        self.W = nn.Linear(in_channels, heads * out_channels, bias=False)
+        self.Wdiag = torch.ones(hyperg.degE.shape[0]).to(hyperg.device)
+        self.heads, self.in_channels, self.out_channels = heads, in_channels, out_channels
+        self.hyperg, self.degE, self.degV = hyperg, hyperg.degE, hyperg.degV
+        self.first_aggr = first_aggr
+
+    def forward(self, X):
+        X = self.W(X)
+        return HGNNAggr(self.hyperg, X, self.degE, self.degV, self.Wdiag, self.first_aggr)
+
+
+class HyperGsysUinGINConv(nn.Module):
+    def __init__(self, hyperg, in_channels, out_channels, first_aggr, heads=1):
+        super().__init__()
+        self.W = nn.Linear(in_channels, heads * out_channels, bias=False)
+        self.heads, self.in_channels, self.out_channels = heads, in_channels, out_channels
+        self.hyperg, self.degE, self.degV = hyperg, hyperg.degE, hyperg.degV
+        self.eps = nn.parameter.Parameter(torch.FloatTensor([0]))
+
+    def forward(self, X):
+        X = self.W(X)
+        Xv = UniGNNConv(self.hyperg, X)
+        return (1 + self.eps) * X + Xv
+
+
+class HyperGsysUniGCNII(nn.Module):
+    def __init__(self, hyperg, in_channels, out_channels, heads=1):
+        super().__init__()
+        self.W = nn.Linear(in_channels, out_channels, bias=False)
+        self.heads, self.in_channels, self.out_channels = heads, in_channels, out_channels
+        self.hyperg, self.degE, self.degV = hyperg, hyperg.degE, hyperg.degV
+
+    def forward(self, X, X0, alpha, beta):
+        Xv = UniGNNConvdeg(self.hyperg, X, self.degE, self.degV)
+        Xi = (1 - alpha) * Xv + alpha * X0
+        return (1 - beta) * Xi + beta * self.W(Xi)
+
+
+# ---- torch index_add baseline (model/pygnn/*.py formulas) ---------------------
+
+class _TorchGraph:
+    """Gather/scatter form of the incidence: V, E index vectors (hypergraph.py:30-32)."""
+
+    def __init__(self, hyperg, device):
+        inc = hyperg._host
+        import numpy as np
+        E = np.repeat(np.arange(inc.M, dtype=np.int64), np.diff(inc.csrptr))
+        self.V = torch.from_numpy(inc.colind.astype(np.int64)).to(device)
+        self.E = torch.from_numpy(E).to(device)
+        self.N, self.M = inc.N, inc.M
+        self.degE = hyperg.degE.to(device)
+        self.degV = hyperg.degV.to(device)
+
+    def v2e(self, X):
+        return torch.zeros(self.M, X.shape[1], dtype=X.dtype, device=X.device).index_add_(0, self.E, X[self.V])
+
+    def e2v(self, Xe):
+        return torch.zeros(self.N, Xe.shape[1], dtype=Xe.dtype, device=Xe.device).index_add_(0, self.V, Xe[self.E])
+
+
+class TorchHGNNConv(nn.Module):
+    def __init__(self, tg, in_channels, out_channels, first_aggr, heads=1):
+        super().__init__()
+        self.linear = nn.Linear(in_channels, heads * out_channels, bias=False)
+        self.tg = tg
+
+    def forward(self, X):
+        X = self.linear(X)
+        Xe = self.tg.v2e(X) * torch.nan_to_num(self.tg.degE, posinf=0.0)
+        return self.tg.e2v(Xe) * self.tg.degV
+
+
+class TorchGINConv(nn.Module):
+    def __init__(self, tg, in_channels, out_channels, first_aggr, heads=1):
+        super().__init__()
+        self.W = nn.Linear(in_channels, heads * out_channels, bias=False)
+        self.eps = nn.parameter.Parameter(torch.FloatTensor([0]))
+        self.tg = tg
+
+    def forward(self, X):
+        X = self.W(X)
+        return (1 + self.eps) * X + self.tg.e2v(self.tg.v2e(X))
+
+
+class TorchGCNIIConv(nn.Module):
+    def __init__(self, tg, in_channels, out_channels, heads=1):
+        super().__init__()
+        self.W = nn.Linear(in_channels, out_channels, bias=False)
+        self.tg = tg
+
+    def forward(self, X, X0, alpha, beta):
+        Xe = self.tg.v2e(X) * torch.nan_to_num(self.tg.degE, posinf=0.0)
+        Xv = self.tg.e2v(Xe) * self.tg.degV
+        Xi = (1 - alpha) * Xv + alpha * X0
+        return (1 - beta) * Xi + beta * self.W(Xi)
+
+
+__hgsys_convs__ = {"UniGIN": HyperGsysUinGINConv, "HGNN": HyperGsysHGNN}
+__torch_convs__ = {"UniGIN": TorchGINConv, "HGNN": TorchHGNNConv}
+
+
+# ---- networks (model/gnn.py) -----------------------------------------------------
+
+class HGsysHGNN(nn.Module):
+    """model/gnn.py:110-134; `args` needs .model, .activation, .input_drop, .dropout
+    (and .backend: 'hgsys' or 'torch')."""
+
+    def __init__(self, args, hyperg, nfeat, nhid, nclass, nlayer, first_aggr, nhead):
+        super().__init__()
+        if getattr(args, "backend", "hgsys") == "torch":
+            Conv, g = __torch_convs__[args.model], _TorchGraph(hyperg, getattr(args, "device", hyperg.device))
+        else:
+            Conv, g = __hgsys_convs__[args.model], hyperg
+        self.conv_out = Conv(g, nhid * nhead, nclass, first_aggr, nhead)
+        self.convs = nn.ModuleList([Conv(g, nfeat, nhid, first_aggr, nhead)] +
+                                   [Conv(g, nhid * nhead, nhid, first_aggr, nhead) for _ in range(nlayer - 2)])
+        self.act = {"relu": nn.ReLU(), "leaky_relu": nn.LeakyReLU()}[args.activation]
+        self.input_drop = nn.Dropout(args.input_drop)
+        self.dropout = nn.Dropout(args.dropout)
+
+    def forward(self, X):
+        X = self.input_drop(X)
+        for conv in self.convs:
+            X = self.dropout(self.act(conv(X)))
+        return F.log_softmax(self.conv_out(X), dim=1)
+
+
+class UniGCNII(nn.Module):
+    """model/gnn.py:137-208."""
+
+    def __init__(self, args, hyperg, nfeat, nhid, nclass, nlayer, nhead):
+        super().__init__()
+        nhid = nhid * nhead
+        self.act = {"relu": nn.ReLU(), "prelu": nn.PReLU()}[args.activation]
+        self.input_drop = nn.Dropout(args.input_drop)
+        self.dropout = nn.Dropout(args.dropout)
+        self.convs = nn.ModuleList([nn.Linear(nfeat, nhid)])
+        if getattr(args, "backend", "hgsys") == "torch":
+            tg = _TorchGraph(hyperg, getattr(args, "device", hyperg.device))
+            self.convs.extend(TorchGCNIIConv(tg, nhid, nhid) for _ in range(nlayer))
+        else:
+            self.convs.extend(HyperGsysUniGCNII(hyperg, nhid, nhid) for _ in range(nlayer))
+        self.convs.append(nn.Linear(nhid, nclass))
+        self.reg_params = list(self.convs[1:-1].parameters())
+        self.non_reg_params = list(self.convs[0:1].parameters()) + list(self.convs[-1:].parameters())
+
+    def forward(self, x):
+        lamda, alpha = 0.5, 0.1
+        x = self.dropout(x)
+        x = F.relu(self.convs[0](x))
+        x0 = x
+        for i, con in enumerate(self.convs[1:-1]):
+            x = self.dropout(x)
+            beta = math.log(lamda / (i + 1) + 1)
+            x = F.relu(con(x, x0, alpha, beta))
+        x = self.dropout(x)
+        return F.log_softmax(self.convs[-1](x), dim=1)

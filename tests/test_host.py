@@ -234,3 +234,31 @@ def test_aggr_proto_cli_cpu_mode(hg, tmp_path):
     assert "start spmm test" in lines and "start fused kernel test" in lines and lines.count("check passed!") == 2
     row = (tmp_path / "result.csv").read_text().strip().split(",")
     assert row[0] == str(mtx) and row[1] == "32" and len(row) == 10
+
+
+def test_models_torch_backend_cpu(hg):
+    """The index_add_ baseline networks build and train on CPU (they stand in for PyG/DGL)."""
+    import argparse
+    import torch
+    from hypergef_amd import models
+    inc = synth.citeseer_shape()
+    hyperg = hg.HyperGraph.from_incidence(inc, "cpu", data_name="citeseer")
+    assert hyperg.group_key.dtype == torch.int32 and hyperg.ngs == 6
+    args = argparse.Namespace(model="HGNN", activation="relu", input_drop=0.0, dropout=0.0, backend="torch",
+                              device="cpu")
+    torch.manual_seed(0)
+    X = torch.randn(inc.N, 12)
+    y = torch.randint(0, 4, (inc.N,))
+    for name in ("HGNN", "UniGIN", "UniGCNII"):
+        args.model = name
+        net = (models.UniGCNII(args, hyperg, 12, 8, 4, 2, 1) if name == "UniGCNII"
+               else models.HGsysHGNN(args, hyperg, 12, 8, 4, 2, "sum", 1))
+        opt = torch.optim.Adam(net.parameters(), lr=0.01)
+        losses = []
+        for _ in range(15):
+            opt.zero_grad()
+            loss = torch.nn.functional.nll_loss(net(X), y)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+        assert np.isfinite(losses).all() and losses[-1] < losses[0]

@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Training / inference timing driver, the reference's `hgsys.py` (which its README
+calls `ugsys.py`) on this backend: same flags (`--model` or `--model-name`, `--backend`,
+`--dname`, `--nhid`, `--nlayer`, `--nhead`, `--first-aggr`, `--epochs`, `--device`,
+`--output`, `--profile`), same loop (10 warm-up epochs, `epochs` timed training epochs
+with Adam(lr=0.01, wd=5e-4) and nll_loss, then `epochs` timed eval passes,
+HyperGsys/hgsys.py:136-211), same CSV line.  Datasets are synthetic:
+`--dname cora|citeseer|pubmed` selects the shape; features / labels are seeded random.
+Backends: `hgsys` (this backend's kernels) and `torch` (index_add_ baseline standing
+in for PyG/DGL, runs on `--device cpu` too).  `--world-size N` under torchrun shards a
+batch of `--replicas` hypergraphs by hypergraph across ranks (data parallel: gradients
+are all-reduced over RCCL).
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import torch.nn.functional as F
+import torch.optim as optim
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--dname", default="cora")
+    p.add_argument("--model", "--model-name", dest="model", type=str, default="HGNN", help="HGNN | UniGIN | UniGCNII")
+    p.add_argument("--activation", type=str, default="relu")
+    p.add_argument("--nlayer", type=int, default=2)
+    p.add_argument("--nhid", type=int, default=32)
+    p.add_argument("--nhead", type=int, default=1)
+    p.add_argument("--nfeat", type=int, default=64, help="synthetic input feature width")
+    p.add_argument("--nclass", type=int, default=7)
+    p.add_argument("--dropout", type=float, default=0.6)
+    p.add_argument("--input-drop", type=float, default=0.6)
+    p.add_argument("--first-aggr", type=str, default="sum")
+    p.add_argument("--lr", type=float, default=0.01)
+    p.add_argument("--wd", type=float, default=5e-4)
+    p.add_argument("--backend", type=str, default="hgsys", help="hgsys | torch")
+    p.add_argument("--epochs", type=int, default=200)
+    p.add_argument("--device", type=str, default="cuda:0")
+    p.add_argument("--seed", type=int, default=1)
+    p.add_argument("--replicas", type=int, default=1, help="hypergraphs in the (block-diagonal) batch")
+    p.add_argument("--train_prop", type=float, default=0.5)
+    p.add_argument("--profile", type=int, default=0)
+    p.add_argument("--output", type=str, default=None)
+    return p.parse_args()
+
+
+def main():
+    args = parse()
+    import torch.distributed as dist
+    import hypergef_amd as hg
+    from hypergef_amd import models, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if args.device.startswith("cuda"):
+            args.device = "cuda:%d" % local
+            torch.cuda.set_device(local)
+        dist.init_process_group("nccl" if args.device.startswith("cuda") else "gloo")
+    torch.manual_seed(args.seed + rank)
+    np.random.seed(args.seed + rank)
+    dev = torch.device(args.device)
+
+    base = {"cora": synth.cora_shape, "citeseer": synth.citeseer_shape, "pubmed": synth.pubmed_shape}[args.dname]()
+    inc = synth.replicate_block_diagonal(base, args.replicas)
+    hyperg = hg.HyperGraph.from_incidence(inc, dev, data_name=args.dname)
+    X = torch.randn(inc.N, args.nfeat, device=dev)
+    y = torch.randint(0, args.nclass, (inc.N,), device=dev)
+    perm = torch.randperm(inc.N, device=dev)
+    train_idx = perm[: int(args.train_prop * inc.N)]
+
+    if args.model != "UniGCNII":
+        model = models.HGsysHGNN(args, hyperg, args.nfeat, args.nhid, args.nclass, args.nlayer,
+                                 args.first_aggr, args.nhead)
+    else:
+        model = models.UniGCNII(args, hyperg, args.nfeat, args.nhid, args.nclass, args.nlayer, args.nhead)
+    model.to(dev)
+    if world > 1:
+        model = torch.nn.parallel.DistributedDataParallel(
+            model, device_ids=[dev.index] if dev.type == "cuda" else None)
+    opti = optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.wd)
+    if rank == 0:
+        print(f"Total Epochs: {args.epochs}")
+        print(f"total_params:{sum(p.numel() for p in model.parameters() if p.requires_grad)}")
+
+    def sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+
+    def train_epoch():
+        model.train()
+        opti.zero_grad()
+        Z = model(X)
+        loss = F.nll_loss(Z[train_idx], y[train_idx])
+        loss.backward()
+        opti.step()
+        return loss
+
+    for _ in range(10):
+        loss = train_epoch()
+    sync()
+    start = time.time()
+    for _ in range(args.epochs):
+        loss = train_epoch()
+    sync()
+    trainTime = (time.time() - start) / args.epochs
+    if args.profile:
+        print(f"epoch time: {trainTime * args.epochs:.4f}")
+        return
+    model.eval()
+    sync()
+    start = time.time()
+    with torch.no_grad():
+        for _ in range(args.epochs):
+            Z = model(X)
+    sync()
+    inferenceTime = (time.time() - start) / args.epochs
+    if rank == 0:
+        assert torch.isfinite(loss), "training diverged"
+        print(f"backend {args.backend}: avg epoch time {trainTime:.4f}")
+        print(f"backend {args.backend}: avg inference time {inferenceTime:.6f} (final loss {loss.item():.4f}, "
+              f"{world} rank(s), {inc.N} vertices / {inc.M} hyperedges / {inc.nnz} incidences per rank)")
+        if args.output is not None:
+            with open(args.output, "a") as f:
+                print(f"{args.backend},{args.model},{args.dname},nlayer={args.nlayer}, nhid={args.nhid}, "
+                      f"nhead={args.nhead},first_aggr={args.first_aggr},{trainTime},{inferenceTime}", file=f)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
