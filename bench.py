@@ -96,6 +96,17 @@ def cpu_baseline(base, inc, F, X_host):
     orc.build()
     # sample: the first S hypergraphs of the batch (whole workload if small)
     blocks = inc.M // base.M
+    if blocks == 1 and inc.nnz > 2_000_000:
+        # one big hypergraph (power-law config): the fused host path costs sum_v sum_e |e| row
+        # reads, minutes at this size; time the reference's other CPU path, two spmm_reference_host
+        # calls (spmm.cuh:724-740), once over the whole graph
+        H_ptr, H_ind = orc.transpose_csr(inc.M, inc.N, inc.csrptr, inc.colind)
+        t0 = time.perf_counter()
+        orc.twostep_host(inc.N, inc.M, F, H_ptr, H_ind, inc.csrptr, inc.colind, X_host)
+        dt = time.perf_counter() - t0
+        return {"value": inc.nnz / dt, "unit": "edges/s", "cores": 1, "kind": "port",
+                "sample": "whole %s hypergraph, F=%d, one pass of the two-step host path (%.2f s)"
+                          % (base.name, F, dt)}
     S = min(blocks, 256)
     Ms, Ns = base.M * S, base.N * S
     ptr = inc.csrptr[:Ms + 1]

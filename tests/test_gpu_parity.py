@@ -396,3 +396,29 @@ def test_models_hgsys_matches_torch_baseline(hg, name):
     assert torch.allclose(outs["hgsys"], outs["torch"], rtol=1e-4, atol=1e-5)
     for a, b in zip(grads["hgsys"], grads["torch"]):
         assert torch.allclose(a, b, rtol=1e-3, atol=1e-5)
+
+
+def test_hipgraph_capture_replay(hg, oracle):
+    """Launch functions only enqueue: once the F-dependent schedule is prepared, an
+    aggregation can be captured into a hipGraph and replayed."""
+    from hypergef_amd.plan import Plan
+    inc = _make("cora")
+    F = 32
+    X, _, _, _, H_ptr, H_ind = _inputs(inc, F, oracle, seed=21)
+    ref = oracle.hyperaggr_host(inc.N, F, H_ptr, H_ind, inc.csrptr, inc.colind, X)
+    ptr, ind = _dev(inc.csrptr), _dev(inc.colind)
+    plan = Plan.from_tensors(inc.N, ptr, ind)
+    plan.prepare(F)
+    x = _dev(X)
+    Y = torch.zeros(inc.N, F, device=DEV)
+    ws = torch.empty(max(plan.workspace_bytes(F), 256), dtype=torch.uint8, device=DEV)
+    for variant in ("pull", "fused"):
+        Y.zero_()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            plan.aggregate(ptr, ind, x, out=Y, workspace=ws, variant=variant)
+        Y.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(Y.cpu().numpy(), ref)
