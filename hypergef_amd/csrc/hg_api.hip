@@ -104,6 +104,8 @@ int fused_upload(hg::FusedSched &f, int64_t &bytes) {
   UP(hub_ptr, d_hub_ptr);
   UP(hub_ind, d_hub_ind);
   UP(hub_vid, d_hub_vid);
+  UP(rec, d_rec);
+  UP(rec_tab, d_rec_tab);
 #undef UP
   if ((rc = sched_upload(f.mat_sched, bytes)) != HG_OK) return rc;
   return sched_upload(f.hub_sched, bytes);
@@ -111,7 +113,7 @@ int fused_upload(hg::FusedSched &f, int64_t &bytes) {
 
 void fused_free(hg::FusedSched &f) {
   void *ptrs[] = {f.d_panels, f.d_soff, f.d_pmem, f.d_slot_eid, f.d_prow, f.d_pend, f.d_pvs, f.d_mat_ptr,
-                  f.d_mat_ind, f.d_mat_eid, f.d_hub_ptr, f.d_hub_ind, f.d_hub_vid};
+                  f.d_mat_ind, f.d_mat_eid, f.d_hub_ptr, f.d_hub_ind, f.d_hub_vid, f.d_rec, f.d_rec_tab};
   for (void *q : ptrs)
     if (q) (void)hipFree(q);
   sched_free(f.mat_sched);
@@ -140,14 +142,15 @@ int get_fused(const hg_plan *cp, int32_t F, bool vec4, bool dma, const hg::Fused
   hg_plan *p = const_cast<hg_plan *>(cp);
   int32_t cap, mem_cap;
   fused_caps(p, F, vec4, dma, cap, mem_cap);
-  const int64_t key = (int64_t)cap * 1000000 + mem_cap;
+  const int32_t ng = 256 / (hg::fused_tile_row_floats(F, vec4) / (vec4 ? 4 : 1));  // lane groups per workgroup
+  const int64_t key = ((int64_t)cap * 1000000 + mem_cap) * 1000 + ng;
   std::lock_guard<std::mutex> lock(p->fused_mu);
   auto it = p->fused.find(key);
   if (it == p->fused.end()) {
     hg::FusedSched f;
     try {
       hg::build_fused(p->N, p->M, p->ptr_t.data(), p->ind_t.data(), p->ptr_v.data(), p->ind_v.data(),
-                      p->opts, cap, mem_cap, f);
+                      p->opts, cap, mem_cap, ng, f);
     } catch (const std::bad_alloc &) {
       hg::set_error("fused schedule: host allocation failed");
       return HG_ERR_NOMEM;
@@ -618,6 +621,10 @@ int hg_aggr_fused_f32(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
     a.vslot_cap = f->vslot_cap;
     a.xcd_remap = (plan->opts.flags & HG_PLAN_NO_XCD_REMAP) ? 0 : 1;
     a.dma = dma ? 1 : 0;
+    a.rec = f->d_rec;
+    a.rec_tab = f->d_rec_tab;
+    a.max_rec_words = f->max_rec_words;
+    a.ng = f->ng;
     hipError_t e = hg::launch_fused(a, vec4, s);
     if (e != hipSuccess) return hip_fail("fused_panel launch", e);
     return HG_OK;

@@ -12,9 +12,11 @@
 
 namespace hg {
 
+void pack_records(FusedSched &f, int32_t ng);
+
 void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_t,
                  const int32_t *ptr_v, const int32_t *ind_v, const Opts &o, int32_t cap,
-                 int32_t mem_cap, FusedSched &f) {
+                 int32_t mem_cap, int32_t ng, FusedSched &f) {
   f = FusedSched();
   f.cap = cap;
   f.rows_cap = cap;
@@ -24,7 +26,6 @@ void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_
   // a single row must always fit into an empty panel
   f.vdeg_max = std::max(1, std::min(std::min(cap, f.vslot_cap), f.mem_cap / f.t_big));
 
-  const int64_t nnz = ptr_t[M];
   std::vector<uint8_t> is_mat((size_t)M, 0), is_hub((size_t)N, 0);
   for (int32_t e = 0; e < M; e++)
     if (ptr_t[e + 1] - ptr_t[e] > f.t_big) is_mat[e] = 1;
@@ -171,6 +172,105 @@ void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_
   }
   close_panel();
   f.pmem_entries = (int64_t)f.pmem.size();
+  pack_records(f, ng);
+}
+
+// One self-contained int32 record per panel for the packed kernel: a header, the
+// hop-1 entry stream laid out [step][group] (the panel's slots are spread over
+// the `ng` lane groups with longest-first greedy packing, so every group walks
+// the same number of steps and the loop is wave-uniform), then the hop-2 lists.
+//   header  : [0] steps  [1] nrows  [2] nslots  [3] nvs
+//             [4] off_gbase [5] off_stream [6] off_pend [7] off_prow [8] off_eid [9] off_pvs
+//   gbase   : ng words, first slot id of each group (a group's slots are numbered in
+//             the order it finishes them)
+//   stream  : steps * ng words; -1 = idle step, else bits 0..29 row index,
+//             bit 30 = row of the materialised table, bit 31 = last entry of its slot
+//   pend    : nrows local end offsets into pvs;  prow: nrows vertex ids
+//   eid     : nslots hyperedge ids in slot order (-1 = materialised, already scaled)
+//   pvs     : nvs slot ids, two 16-bit values per word
+void pack_records(FusedSched &f, int32_t ng) {
+  f.ng = ng;
+  f.rec.clear();
+  f.rec_tab.clear();
+  f.max_rec_words = 0;
+  f.stream_entries = 0;
+  std::vector<int32_t> order, load, gslots, newid, stream;
+  for (const FPanel &pn : f.panels) {
+    const int32_t *soff = f.soff.data() + pn.sbase;
+    const int32_t *pm = f.pmem.data() + pn.pm0;
+    // longest slot first, each to the least loaded group
+    order.resize((size_t)pn.nslots);
+    for (int32_t k = 0; k < pn.nslots; k++) order[k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+      return (soff[x + 1] - soff[x]) > (soff[y + 1] - soff[y]);
+    });
+    load.assign((size_t)ng, 0);
+    std::vector<std::vector<int32_t>> members((size_t)ng);
+    for (int32_t k : order) {
+      int32_t best = 0;
+      for (int32_t g = 1; g < ng; g++)
+        if (load[g] < load[best]) best = g;
+      members[best].push_back(k);
+      load[best] += soff[k + 1] - soff[k];
+    }
+    int32_t steps = 0;
+    for (int32_t g = 0; g < ng; g++) steps = std::max(steps, load[g]);
+    // slot ids in (group, completion order); streams
+    newid.assign((size_t)pn.nslots, 0);
+    gslots.assign((size_t)ng, 0);
+    stream.assign((size_t)steps * ng, -1);
+    int32_t next = 0;
+    std::vector<int32_t> eid((size_t)pn.nslots);
+    for (int32_t g = 0; g < ng; g++) {
+      gslots[g] = next;
+      int32_t s = 0;
+      for (int32_t k : members[g]) {
+        newid[k] = next;
+        eid[next] = f.slot_eid[pn.eid0 + k];
+        next++;
+        for (int32_t p = soff[k]; p < soff[k + 1]; p++, s++) {
+          uint32_t w = (uint32_t)pm[p];
+          const uint32_t row = w & 0x3fffffffu;
+          const uint32_t mat = (w & 0x80000000u) ? 0x40000000u : 0u;
+          const uint32_t last = (p + 1 == soff[k + 1]) ? 0x80000000u : 0u;
+          stream[(size_t)s * ng + g] = (int32_t)(row | mat | last);
+        }
+      }
+    }
+    const int32_t hdr = 16;
+    const int32_t off_gbase = hdr, off_stream = off_gbase + ng, off_pend = off_stream + steps * ng;
+    const int32_t off_prow = off_pend + pn.nrows, off_eid = off_prow + pn.nrows;
+    const int32_t off_pvs = off_eid + pn.nslots;
+    const int32_t words = off_pvs + (pn.nvs + 1) / 2;
+    FRec rt;
+    rt.off = (int64_t)f.rec.size();
+    rt.len = words;
+    f.rec_tab.push_back(rt);
+    f.max_rec_words = std::max(f.max_rec_words, words);
+    f.stream_entries += (int64_t)steps * ng;
+    const size_t base = f.rec.size();
+    f.rec.resize(base + (size_t)words, 0);
+    int32_t *r = f.rec.data() + base;
+    r[0] = steps;
+    r[1] = pn.nrows;
+    r[2] = pn.nslots;
+    r[3] = pn.nvs;
+    r[4] = off_gbase;
+    r[5] = off_stream;
+    r[6] = off_pend;
+    r[7] = off_prow;
+    r[8] = off_eid;
+    r[9] = off_pvs;
+    for (int32_t g = 0; g < ng; g++) r[off_gbase + g] = gslots[g];
+    std::copy(stream.begin(), stream.end(), r + off_stream);
+    for (int32_t i = 0; i < pn.nrows; i++) {
+      r[off_pend + i] = f.pend[pn.r0 + i];
+      r[off_prow + i] = f.prow[pn.r0 + i];
+    }
+    for (int32_t k = 0; k < pn.nslots; k++) r[off_eid + k] = eid[k];
+    uint16_t *pv = reinterpret_cast<uint16_t *>(r + off_pvs);
+    for (int32_t i = 0; i < pn.nvs; i++) pv[i] = (uint16_t)newid[f.pvs[pn.v0 + i]];
+  }
 }
 
 }  // namespace hg

@@ -54,6 +54,12 @@ struct FPanel {
   int32_t r0, nrows, sbase, nslots, pm0, npm, eid0, v0, nvs, pad0, pad1, pad2;
 };
 
+struct FRec {
+  int64_t off;  // word offset of the panel's record
+  int32_t len;  // record length in words
+  int32_t pad;
+};
+
 struct FusedSched {
   int32_t cap = 0;        // slots per panel (LDS tile rows)
   int32_t rows_cap = 0;   // rows per panel
@@ -78,6 +84,14 @@ struct FusedSched {
   int32_t *d_mat_ptr = nullptr, *d_mat_ind = nullptr, *d_mat_eid = nullptr;
   int32_t *d_hub_ptr = nullptr, *d_hub_ind = nullptr, *d_hub_vid = nullptr;
   int64_t pmem_entries = 0;
+  // packed per-panel records (see pack_records in hg_fused.cpp)
+  int32_t ng = 0;             // lane groups the hop-1 stream is packed for
+  std::vector<int32_t> rec;   // all records, back to back
+  std::vector<FRec> rec_tab;  // per panel: offset and length in words
+  int32_t max_rec_words = 0;
+  int64_t stream_entries = 0;  // steps * ng summed over panels (incl. idle steps)
+  int32_t *d_rec = nullptr;
+  FRec *d_rec_tab = nullptr;
 };
 
 struct Opts {
@@ -105,7 +119,7 @@ void transpose_csr(int32_t nrows, int32_t ncols, const int32_t *ptr,
 void build_sched(int32_t nrows, const int32_t *ptr, const Opts &o, Sched &s);
 void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_t,
                  const int32_t *ptr_v, const int32_t *ind_v, const Opts &o, int32_t cap,
-                 int32_t mem_cap, FusedSched &f);
+                 int32_t mem_cap, int32_t ng, FusedSched &f);
 
 }  // namespace hg
 

@@ -37,6 +37,10 @@ struct FusedArgs {
   int32_t F;
   int32_t cap, rows_cap, mem_cap, vslot_cap;
   int32_t xcd_remap;
+  const int32_t *rec;     // packed per-panel records
+  const FRec *rec_tab;    // per panel: record offset / length
+  int32_t max_rec_words;  // LDS space for one record
+  int32_t ng;             // lane groups the records were packed for
   int32_t dma;  // 1: LDS-DMA kernel, 0: register-staged kernel
   int32_t debug = 0;  // ablation bits (experiments only)
 };

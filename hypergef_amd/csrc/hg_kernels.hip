@@ -467,6 +467,109 @@ __global__ __launch_bounds__(256) void fused_dma_kernel(const FusedArgs a) {
   }
 }
 
+// Packed form of the fused panel kernel.  The plan hands every panel over as ONE
+// contiguous int32 record (hg_fused.cpp, pack_records): a single coalesced copy
+// stages it, and hop 1 is a wave-uniform loop over a [step][group] entry stream in
+// which the panel's hyperedge slots were packed longest-first over the lane
+// groups -- no per-group offsets to look up, no divergent trip counts, the same
+// number of row gathers for every group.  Entry word: -1 idle, else bits 0..29 =
+// row, bit 30 = row of the materialised table, bit 31 = last member of its slot
+// (scale, store to the LDS tile, start the next slot).  Members of a slot stay in
+// their CSR order, so the arithmetic is still the CPU reference's.
+template <int LPR, int VEC, int U>
+__global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
+  constexpr int BS = 256;
+  constexpr int NG = BS / LPR;
+  constexpr int TW = LPR * VEC;
+  using V = Vec<VEC>;
+  extern __shared__ int32_t smem[];
+  const int tid = threadIdx.x;
+  const int gl = tid & (LPR - 1);
+  const int lcol = gl * VEC;
+  const int col = blockIdx.y * TW + lcol;
+  const bool col_ok = col < a.F;
+  const int64_t F = a.F;
+  int b = blockIdx.x;
+  if (a.xcd_remap) {
+    const int x = b & 7, i = b >> 3;
+    const int cpx = a.npanels >> 3, rem = a.npanels & 7;
+    b = x * cpx + (x < rem ? x : rem) + i;
+  }
+  const FRec rt = a.rec_tab[b];
+  const int32_t *grec = a.rec + rt.off;
+
+  float *tile = reinterpret_cast<float *>(smem);        // [cap * TW]
+  int32_t *rec = smem + a.cap * TW;                      // [max_rec_words]
+  float *sA = reinterpret_cast<float *>(rec + a.max_rec_words);  // [cap]
+  float *sB = sA + a.cap;                                // [cap]
+  float *sdeg = sB + a.cap;                              // [rows_cap]
+
+  for (int i = tid; i < rt.len; i += BS) rec[i] = grec[i];
+  __syncthreads();
+  const int steps = rec[0], nrows = rec[1], nslots = rec[2];
+  const int32_t *gbase = rec + rec[4];
+  const int32_t *stream = rec + rec[5];
+  const int32_t *pend = rec + rec[6];
+  const int32_t *prow = rec + rec[7];
+  const int32_t *eid = rec + rec[8];
+  const uint16_t *pvs = reinterpret_cast<const uint16_t *>(rec + rec[9]);
+  if (a.degE || a.W || a.degV) {
+    if (a.degE || a.W)
+      for (int i = tid; i < nslots; i += BS) {
+        const int e = eid[i];  // -1: materialised row, already scaled
+        sA[i] = (a.degE && e >= 0) ? a.degE[e] : 1.f;
+        sB[i] = (a.W && e >= 0) ? a.W[e] : 1.f;
+      }
+    if (a.degV)
+      for (int i = tid; i < nrows; i += BS) sdeg[i] = a.degV[prow[i]];
+    __syncthreads();
+  }
+
+  const int g = tid / LPR;
+  {  // ---- hop 1
+    int slot = gbase[g];
+    V acc = V::zero();
+    for (int s0 = 0; s0 < steps; s0 += U) {
+      int ent[U];
+#pragma unroll
+      for (int j = 0; j < U; j++) ent[j] = (s0 + j < steps) ? stream[(s0 + j) * NG + g] : -1;
+      V v[U];
+#pragma unroll
+      for (int j = 0; j < U; j++) {
+        const bool on = col_ok && ent[j] != -1;
+        const int64_t idx = ent[j] & 0x3fffffff;
+        const float *base = (a.Xe_mat && (ent[j] & 0x40000000)) ? a.Xe_mat : a.X;
+        v[j] = on ? V::load(base + idx * F + col) : V::zero();
+      }
+#pragma unroll
+      for (int j = 0; j < U; j++) {
+        if (ent[j] != -1) {
+          acc.add(v[j]);
+          if (ent[j] < 0) {  // last member of this slot
+            if (a.degE) acc.mul(sA[slot]);
+            if (a.W) acc.mul(sB[slot]);
+            acc.store(tile + slot * TW + lcol);
+            slot++;
+            acc = V::zero();
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  {  // ---- hop 2
+    const int rpg = (nrows + NG - 1) / NG;
+    const int r0 = min(g * rpg, nrows), r1 = min(r0 + rpg, nrows);
+    for (int r = r0; r < r1; r++) {
+      V acc = V::zero();
+      const int pb = r ? pend[r - 1] : 0, pe = pend[r];
+      for (int p = pb; p < pe; p++) acc.add(V::load(tile + (int)pvs[p] * TW + lcol));
+      if (a.degV && pe > pb) acc.mul(sdeg[r]);
+      if (col_ok) acc.store(a.Y + (int64_t)prow[r] * F + col);
+    }
+  }
+}
+
 // Persistent, software-pipelined form of fused_panel_kernel.  A workgroup walks a
 // strided sequence of its XCD's panels; while it gathers and sums panel i, the
 // lists of panel i+1 are already in flight (into registers, written to LDS when
@@ -939,6 +1042,7 @@ struct Tuning {
   int fused_dma = 0;
   int fused_persist = 0;
   int fused_ws = 0;
+  int fused_packed = 1;
   int fused_grid = 0;
   int fused_debug = 0;  // ablation bits for fused_panel_kernel (timing experiments only)
 };
@@ -953,6 +1057,7 @@ static const Tuning &tuning() {
     if (const char *e = getenv("HG_FUSED_DMA")) x.fused_dma = atoi(e) != 0;
     if (const char *e = getenv("HG_FUSED_PERSIST")) x.fused_persist = atoi(e) != 0;
     if (const char *e = getenv("HG_FUSED_WS")) x.fused_ws = atoi(e) != 0;
+    if (const char *e = getenv("HG_FUSED_PACKED")) x.fused_packed = atoi(e) != 0;
     if (const char *e = getenv("HG_FUSED_GRID")) x.fused_grid = atoi(e);
     if (const char *e = getenv("HG_FUSED_DEBUG")) x.fused_debug = atoi(e);
     return x;
@@ -1031,6 +1136,17 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || num_cu <= 0)
       num_cu = 256;
+  }
+  if (t.fused_packed && a.ng == 256 / LPR) {
+    const size_t lds_p = (size_t)a.cap * TW * 4 + (size_t)a.max_rec_words * 4 +
+                         (size_t)(2 * a.cap + a.rows_cap) * 4 + 16;
+    if (t.fused_u == 8)
+      hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 8>), grid, dim3(256), lds_p, stream, a);
+    else if (t.fused_u == 6)
+      hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 6>), grid, dim3(256), lds_p, stream, a);
+    else
+      hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 4>), grid, dim3(256), lds_p, stream, a);
+    return hipGetLastError();
   }
   if (t.fused_ws) {
     // wave-specialised persistent kernel: 4 compute waves + 1 loader wave, two list buffers.
