@@ -176,7 +176,7 @@ int get_fused(const hg_plan *cp, int32_t F, bool vec4, bool dma, const hg::Fused
 
 // workspace carve-up: [Xe: M*F][partials hop 0][partials hop 1]
 struct Carve {
-  size_t xe, part[2], total;
+  size_t xe, part[2], ctr, total;
 };
 Carve carve(const hg_plan *p, int32_t F) {
   Carve c;
@@ -186,6 +186,8 @@ Carve carve(const hg_plan *p, int32_t F) {
     c.part[h] = off;
     off += round256((size_t)p->sched[h].nslots * F * sizeof(float));
   }
+  c.ctr = off;  // 8 work counters, one per XCD class, 64 bytes apart
+  off += 512;
   c.total = off;
   return c;
 }
@@ -625,6 +627,7 @@ int hg_aggr_fused_f32(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
     a.rec_tab = f->d_rec_tab;
     a.max_rec_words = f->max_rec_words;
     a.ng = f->ng;
+    a.counters = reinterpret_cast<int32_t *>(ws + c.ctr);
     hipError_t e = hg::launch_fused(a, vec4, s);
     if (e != hipSuccess) return hip_fail("fused_panel launch", e);
     return HG_OK;

@@ -41,6 +41,7 @@ struct FusedArgs {
   const FRec *rec_tab;    // per panel: record offset / length
   int32_t max_rec_words;  // LDS space for one record
   int32_t ng;             // lane groups the records were packed for
+  int32_t *counters;      // 8 x 16 ints of per-XCD-class work counters (persistent kernel)
   int32_t dma;  // 1: LDS-DMA kernel, 0: register-staged kernel
   int32_t debug = 0;  // ablation bits (experiments only)
 };

@@ -570,6 +570,152 @@ __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
   }
 }
 
+__device__ __forceinline__ void dma_copy_dwords(const int32_t *src, int32_t *dst, int n, int lane);
+
+// Wave-specialised persistent form of fused_packed_kernel: 4 compute waves + 1
+// loader wave, two record buffers in LDS.  The loader wave draws the next panel of
+// its XCD class from a per-class counter in global memory (dynamic, so the grid
+// may be any size >= what the chip holds), copies that panel's record into the
+// idle buffer by LDS-DMA and gathers its scales, all while the compute waves work
+// on the current buffer: descriptor, record and scale latencies are off the
+// compute waves' critical path, and because a wave's memory counter is its own,
+// the loader's loads never queue ahead of the compute waves' row gathers.
+template <int LPR, int VEC, int U>
+__global__ __launch_bounds__(320) void fused_packed_ws_kernel(const FusedArgs a) {
+  constexpr int CT = 256;
+  constexpr int NG = CT / LPR;
+  constexpr int TW = LPR * VEC;
+  using V = Vec<VEC>;
+  extern __shared__ int32_t smem[];
+  const int tid = threadIdx.x;
+  const bool loader = tid >= CT;
+  const int64_t F = a.F;
+
+  // this workgroup's class of panels (one contiguous eighth per XCD class)
+  int cls, start, end;
+  {
+    const int x = blockIdx.x & 7;
+    const int cpx = a.npanels >> 3, rem = a.npanels & 7;
+    cls = x;
+    start = x * cpx + (x < rem ? x : rem);
+    end = start + cpx + (x < rem ? 1 : 0);
+  }
+
+  float *tile = reinterpret_cast<float *>(smem);  // [cap * TW]
+  const int bufw = a.max_rec_words + 2 * a.cap + a.rows_cap;  // words per buffer
+  int32_t *buf0 = smem + a.cap * TW, *buf1 = buf0 + bufw;
+  const bool weighted = a.degE || a.W || a.degV;
+
+  // loader wave: draw a panel, start copying its record into `buf`; returns the record length
+  // (0 = class exhausted; rec[0] = -1 then tells the compute waves to stop)
+  auto start_load = [&](int32_t *buf, int lane) -> int {
+    int idx = 0;
+    if (lane == 0) idx = atomicAdd(a.counters + cls * 16, 1);
+    idx = __builtin_amdgcn_readfirstlane(idx) + start;
+    if (idx >= end) {
+      if (lane == 0) buf[0] = -1;
+      return 0;
+    }
+    const FRec rt = a.rec_tab[idx];
+    dma_copy_dwords(a.rec + rt.off, buf, rt.len, lane);
+    return rt.len;
+  };
+  auto finish_load = [&](int32_t *buf, int len, int lane) {
+    if (len == 0) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!weighted) return;
+    const int nrows = buf[1], nslots = buf[2];
+    const int32_t *prow = buf + buf[7];
+    const int32_t *eid = buf + buf[8];
+    float *sA = reinterpret_cast<float *>(buf + a.max_rec_words), *sB = sA + a.cap, *sdeg = sB + a.cap;
+    if (a.degE || a.W)
+      for (int i = lane; i < nslots; i += 64) {
+        const int e = eid[i];
+        sA[i] = (a.degE && e >= 0) ? a.degE[e] : 1.f;
+        sB[i] = (a.W && e >= 0) ? a.W[e] : 1.f;
+      }
+    if (a.degV)
+      for (int i = lane; i < nrows; i += 64) sdeg[i] = a.degV[prow[i]];
+  };
+
+  if (loader) {
+    const int lane = tid - CT;
+    const int len = start_load(buf0, lane);
+    finish_load(buf0, len, lane);
+  }
+  __syncthreads();
+
+  for (int it = 0;; it++) {
+    int32_t *rec = (it & 1) ? buf1 : buf0;
+    int32_t *nxt = (it & 1) ? buf0 : buf1;
+    const int steps = rec[0];
+    if (steps < 0) break;  // same LDS word for every wave: uniform exit
+    if (loader) {
+      const int lane = tid - CT;
+      const int len = start_load(nxt, lane);
+      __syncthreads();  // (M)
+      finish_load(nxt, len, lane);
+      __syncthreads();  // (X)
+      continue;
+    }
+    const int gl = tid & (LPR - 1);
+    const int lcol = gl * VEC;
+    const int col = blockIdx.y * TW + lcol;
+    const bool col_ok = col < a.F;
+    const int g = tid / LPR;
+    const int nrows = rec[1];
+    const int32_t *gbase = rec + rec[4];
+    const int32_t *stream = rec + rec[5];
+    const int32_t *pend = rec + rec[6];
+    const int32_t *prow = rec + rec[7];
+    const uint16_t *pvs = reinterpret_cast<const uint16_t *>(rec + rec[9]);
+    const float *sA = reinterpret_cast<const float *>(rec + a.max_rec_words), *sB = sA + a.cap, *sdeg = sB + a.cap;
+    {  // ---- hop 1
+      int slot = gbase[g];
+      V acc = V::zero();
+      for (int s0 = 0; s0 < steps; s0 += U) {
+        int ent[U];
+#pragma unroll
+        for (int j = 0; j < U; j++) ent[j] = (s0 + j < steps) ? stream[(s0 + j) * NG + g] : -1;
+        V v[U];
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+          const bool on = col_ok && ent[j] != -1;
+          const int64_t idx = ent[j] & 0x3fffffff;
+          const float *base = (a.Xe_mat && (ent[j] & 0x40000000)) ? a.Xe_mat : a.X;
+          v[j] = on ? V::load(base + idx * F + col) : V::zero();
+        }
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+          if (ent[j] != -1) {
+            acc.add(v[j]);
+            if (ent[j] < 0) {
+              if (a.degE) acc.mul(sA[slot]);
+              if (a.W) acc.mul(sB[slot]);
+              acc.store(tile + slot * TW + lcol);
+              slot++;
+              acc = V::zero();
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();  // (M)
+    {  // ---- hop 2
+      const int rpg = (nrows + NG - 1) / NG;
+      const int r0 = min(g * rpg, nrows), r1 = min(r0 + rpg, nrows);
+      for (int r = r0; r < r1; r++) {
+        V acc = V::zero();
+        const int pb = r ? pend[r - 1] : 0, pe = pend[r];
+        for (int p = pb; p < pe; p++) acc.add(V::load(tile + (int)pvs[p] * TW + lcol));
+        if (a.degV && pe > pb) acc.mul(sdeg[r]);
+        if (col_ok) acc.store(a.Y + (int64_t)prow[r] * F + col);
+      }
+    }
+    __syncthreads();  // (X)
+  }
+}
+
 // Persistent, software-pipelined form of fused_panel_kernel.  A workgroup walks a
 // strided sequence of its XCD's panels; while it gathers and sums panel i, the
 // lists of panel i+1 are already in flight (into registers, written to LDS when
@@ -1057,7 +1203,7 @@ static const Tuning &tuning() {
     if (const char *e = getenv("HG_FUSED_DMA")) x.fused_dma = atoi(e) != 0;
     if (const char *e = getenv("HG_FUSED_PERSIST")) x.fused_persist = atoi(e) != 0;
     if (const char *e = getenv("HG_FUSED_WS")) x.fused_ws = atoi(e) != 0;
-    if (const char *e = getenv("HG_FUSED_PACKED")) x.fused_packed = atoi(e) != 0;
+    if (const char *e = getenv("HG_FUSED_PACKED")) x.fused_packed = atoi(e);
     if (const char *e = getenv("HG_FUSED_GRID")) x.fused_grid = atoi(e);
     if (const char *e = getenv("HG_FUSED_DEBUG")) x.fused_debug = atoi(e);
     return x;
@@ -1136,6 +1282,23 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || num_cu <= 0)
       num_cu = 256;
+  }
+  if (t.fused_packed == 2 && a.ng == 256 / LPR) {
+    // persistent + loader wave; work is drawn from per-class counters, so any grid that
+    // covers the chip works (surplus workgroups find their class empty and leave)
+    const size_t bufw = (size_t)a.max_rec_words + 2 * a.cap + a.rows_cap;
+    const size_t lds_w = (size_t)a.cap * TW * 4 + 2 * bufw * 4 + 16;
+    hipError_t e = hipMemsetAsync(a.counters, 0, 512, stream);
+    if (e != hipSuccess) return e;
+    int per_cu = (int)std::min<size_t>(6, (160 * 1024) / (lds_w + 256));
+    if (per_cu < 1) per_cu = 1;
+    const int want = t.fused_grid > 0 ? t.fused_grid : num_cu * per_cu;
+    const int nwg = std::max(8, std::min((a.npanels + 7) / 8 * 8, want));
+    if (t.fused_u == 8)
+      hipLaunchKernelGGL((fused_packed_ws_kernel<LPR, VEC, 8>), dim3(nwg, col_tiles), dim3(320), lds_w, stream, a);
+    else
+      hipLaunchKernelGGL((fused_packed_ws_kernel<LPR, VEC, 4>), dim3(nwg, col_tiles), dim3(320), lds_w, stream, a);
+    return hipGetLastError();
   }
   if (t.fused_packed && a.ng == 256 / LPR) {
     const size_t lds_p = (size_t)a.cap * TW * 4 + (size_t)a.max_rec_words * 4 +
