@@ -506,6 +506,7 @@ __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
 
   for (int i = tid; i < rt.len; i += BS) rec[i] = grec[i];
   __syncthreads();
+  if (a.debug & 16) return;  // ablation (experiments): record copy only
   const int steps = rec[0], nrows = rec[1], nslots = rec[2];
   const int32_t *gbase = rec + rec[4];
   const int32_t *stream = rec + rec[5];
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
   }
 
   const int g = tid / LPR;
-  {  // ---- hop 1
+  if (!(a.debug & 4)) {  // ---- hop 1
     int slot = gbase[g];
     V acc = V::zero();
     for (int s0 = 0; s0 < steps; s0 += U) {
@@ -539,7 +540,7 @@ __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
         const bool on = col_ok && ent[j] != -1;
         const int64_t idx = ent[j] & 0x3fffffff;
         const float *base = (a.Xe_mat && (ent[j] & 0x40000000)) ? a.Xe_mat : a.X;
-        v[j] = on ? V::load(base + idx * F + col) : V::zero();
+        v[j] = (on && !(a.debug & 1)) ? V::load(base + idx * F + col) : V::zero();
       }
 #pragma unroll
       for (int j = 0; j < U; j++) {
@@ -557,7 +558,7 @@ __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
     }
   }
   __syncthreads();
-  {  // ---- hop 2
+  if (!(a.debug & 8)) {  // ---- hop 2
     const int rpg = (nrows + NG - 1) / NG;
     const int r0 = min(g * rpg, nrows), r1 = min(r0 + rpg, nrows);
     for (int r = r0; r < r1; r++) {
@@ -565,7 +566,7 @@ __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
       const int pb = r ? pend[r - 1] : 0, pe = pend[r];
       for (int p = pb; p < pe; p++) acc.add(V::load(tile + (int)pvs[p] * TW + lcol));
       if (a.degV && pe > pb) acc.mul(sdeg[r]);
-      if (col_ok) acc.store(a.Y + (int64_t)prow[r] * F + col);
+      if (col_ok && !(a.debug & 2)) acc.store(a.Y + (int64_t)prow[r] * F + col);
     }
   }
 }
@@ -1184,7 +1185,7 @@ struct Tuning {
   int unroll = 4;
   int pipe = 0;
   int fused_bs = 256;
-  int fused_u = 4;
+  int fused_u = 8;
   int fused_dma = 0;
   int fused_persist = 0;
   int fused_ws = 0;
@@ -1303,12 +1304,12 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
   if (t.fused_packed && a.ng == 256 / LPR) {
     const size_t lds_p = (size_t)a.cap * TW * 4 + (size_t)a.max_rec_words * 4 +
                          (size_t)(2 * a.cap + a.rows_cap) * 4 + 16;
-    if (t.fused_u == 8)
-      hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 8>), grid, dim3(256), lds_p, stream, a);
-    else if (t.fused_u == 6)
-      hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 6>), grid, dim3(256), lds_p, stream, a);
+    FusedArgs ap = a;
+    ap.debug = t.fused_debug;
+    if (t.fused_u == 4)
+      hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 4>), grid, dim3(256), lds_p, stream, ap);
     else
-      hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 4>), grid, dim3(256), lds_p, stream, a);
+      hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 8>), grid, dim3(256), lds_p, stream, ap);
     return hipGetLastError();
   }
   if (t.fused_ws) {
