@@ -681,7 +681,7 @@ __global__ __launch_bounds__(320) void fused_packed_ws_kernel(const FusedArgs a)
         V v[U];
 #pragma unroll
         for (int j = 0; j < U; j++) {
-          const bool on = col_ok && ent[j] != -1;
+          const bool on = col_ok && ent[j] != -1 && !(a.debug & 1);
           const int64_t idx = ent[j] & 0x3fffffff;
           const float *base = (a.Xe_mat && (ent[j] & 0x40000000)) ? a.Xe_mat : a.X;
           v[j] = on ? V::load(base + idx * F + col) : V::zero();
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(320) void fused_packed_ws_kernel(const FusedArgs a)
         const int pb = r ? pend[r - 1] : 0, pe = pend[r];
         for (int p = pb; p < pe; p++) acc.add(V::load(tile + (int)pvs[p] * TW + lcol));
         if (a.degV && pe > pb) acc.mul(sdeg[r]);
-        if (col_ok) acc.store(a.Y + (int64_t)prow[r] * F + col);
+        if (col_ok && !(a.debug & 2)) acc.store(a.Y + (int64_t)prow[r] * F + col);
       }
     }
     __syncthreads();  // (X)
@@ -1295,10 +1295,12 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
     if (per_cu < 1) per_cu = 1;
     const int want = t.fused_grid > 0 ? t.fused_grid : num_cu * per_cu;
     const int nwg = std::max(8, std::min((a.npanels + 7) / 8 * 8, want));
+    FusedArgs aw = a;
+    aw.debug = t.fused_debug;
     if (t.fused_u == 8)
-      hipLaunchKernelGGL((fused_packed_ws_kernel<LPR, VEC, 8>), dim3(nwg, col_tiles), dim3(320), lds_w, stream, a);
+      hipLaunchKernelGGL((fused_packed_ws_kernel<LPR, VEC, 8>), dim3(nwg, col_tiles), dim3(320), lds_w, stream, aw);
     else
-      hipLaunchKernelGGL((fused_packed_ws_kernel<LPR, VEC, 4>), dim3(nwg, col_tiles), dim3(320), lds_w, stream, a);
+      hipLaunchKernelGGL((fused_packed_ws_kernel<LPR, VEC, 4>), dim3(nwg, col_tiles), dim3(320), lds_w, stream, aw);
     return hipGetLastError();
   }
   if (t.fused_packed && a.ng == 256 / LPR) {
