@@ -611,7 +611,7 @@ int hg_aggr_fused_f32(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
     a.pend = f->d_pend;
     a.pvs = f->d_pvs;
     a.X = X;
-    a.Xe_mat = Xe;
+    a.Xe_mat = f->n_mat > 0 ? Xe : nullptr;  // null = no materialised rows: kernels skip that path
     a.degE = degE;
     a.W = W;
     a.degV = degV;
@@ -628,6 +628,10 @@ int hg_aggr_fused_f32(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
     a.max_rec_words = f->max_rec_words;
     a.ng = f->ng;
     a.counters = reinterpret_cast<int32_t *>(ws + c.ctr);
+    const int64_t xb = (int64_t)plan->N * F * 4, mb = (int64_t)f->n_mat * F * 4;
+    a.x_bytes = xb < ((int64_t)1 << 31) ? (int32_t)xb : 0;
+    a.mat_bytes = mb < ((int64_t)1 << 31) ? (int32_t)mb : 0;
+    a.nrows_x = plan->N;
     hipError_t e = hg::launch_fused(a, vec4, s);
     if (e != hipSuccess) return hip_fail("fused_panel launch", e);
     return HG_OK;

@@ -241,7 +241,7 @@ void pack_records(FusedSched &f, int32_t ng) {
     const int32_t off_gbase = hdr, off_stream = off_gbase + ng, off_pend = off_stream + steps * ng;
     const int32_t off_prow = off_pend + pn.nrows, off_eid = off_prow + pn.nrows;
     const int32_t off_pvs = off_eid + pn.nslots;
-    const int32_t words = off_pvs + (pn.nvs + 1) / 2;
+    const int32_t words = (off_pvs + (pn.nvs + 1) / 2 + 3) & ~3;  // whole 16-byte units
     FRec rt;
     rt.off = (int64_t)f.rec.size();
     rt.len = words;

@@ -42,6 +42,9 @@ struct FusedArgs {
   int32_t max_rec_words;  // LDS space for one record
   int32_t ng;             // lane groups the records were packed for
   int32_t *counters;      // 8 x 16 ints of per-XCD-class work counters (persistent kernel)
+  int32_t x_bytes;        // byte size of X if it fits a buffer descriptor (< 2 GiB), else 0
+  int32_t mat_bytes;      // same for the materialised table
+  int32_t nrows_x;        // rows of X
   int32_t dma;  // 1: LDS-DMA kernel, 0: register-staged kernel
   int32_t debug = 0;  // ablation bits (experiments only)
 };

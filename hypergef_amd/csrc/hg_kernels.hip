@@ -476,7 +476,15 @@ __global__ __launch_bounds__(256) void fused_dma_kernel(const FusedArgs a) {
 // row, bit 30 = row of the materialised table, bit 31 = last member of its slot
 // (scale, store to the LDS tile, start the next slot).  Members of a slot stay in
 // their CSR order, so the arithmetic is still the CPU reference's.
-template <int LPR, int VEC, int U>
+typedef unsigned hg_u4 __attribute__((ext_vector_type(4)));
+typedef int hg_i4 __attribute__((ext_vector_type(4)));
+
+// FAST (VEC = 4 only): rows are fetched with buffer_load_dwordx4 through a buffer
+// descriptor and a 32-bit byte offset formed by one v_mad_u32_u24 (row * row_bytes +
+// column bytes) instead of 64-bit pointer arithmetic; needs N < 2^24, F*4 < 2^24 and
+// tables below 2 GiB (the launcher checks; otherwise FAST = false runs the same loop
+// on global loads).
+template <int LPR, int VEC, int U, bool FAST>
 __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
   constexpr int BS = 256;
   constexpr int NG = BS / LPR;
@@ -499,12 +507,14 @@ __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
   const int32_t *grec = a.rec + rt.off;
 
   float *tile = reinterpret_cast<float *>(smem);        // [cap * TW]
-  int32_t *rec = smem + a.cap * TW;                      // [max_rec_words]
+  int32_t *rec = smem + a.cap * TW;                      // [max_rec_words], 16-byte aligned
   float *sA = reinterpret_cast<float *>(rec + a.max_rec_words);  // [cap]
   float *sB = sA + a.cap;                                // [cap]
   float *sdeg = sB + a.cap;                              // [rows_cap]
 
-  for (int i = tid; i < rt.len; i += BS) rec[i] = grec[i];
+  // records are padded to whole 16-byte units: one dwordx4 per lane copies 4 KB per pass
+  for (int i = tid; i < (rt.len >> 2); i += BS)
+    reinterpret_cast<hg_i4 *>(rec)[i] = reinterpret_cast<const hg_i4 *>(grec)[i];
   __syncthreads();
   if (a.debug & 16) return;  // ablation (experiments): record copy only
   const int steps = rec[0], nrows = rec[1], nslots = rec[2];
@@ -530,6 +540,13 @@ __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
   if (!(a.debug & 4)) {  // ---- hop 1
     int slot = gbase[g];
     V acc = V::zero();
+    [[maybe_unused]] const unsigned row_bytes = (unsigned)a.F * 4u, col_bytes = (unsigned)col * 4u;
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t rx, rm;
+    if constexpr (FAST) {
+      rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.X), 0, a.x_bytes, 0x00020000);
+      rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.Xe_mat ? a.Xe_mat : a.X), 0,
+                                             a.Xe_mat ? a.mat_bytes : 0, 0x00020000);
+    }
     for (int s0 = 0; s0 < steps; s0 += U) {
       int ent[U];
 #pragma unroll
@@ -537,22 +554,31 @@ __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
       V v[U];
 #pragma unroll
       for (int j = 0; j < U; j++) {
-        const bool on = col_ok && ent[j] != -1;
-        const int64_t idx = ent[j] & 0x3fffffff;
-        const float *base = (a.Xe_mat && (ent[j] & 0x40000000)) ? a.Xe_mat : a.X;
-        v[j] = (on && !(a.debug & 1)) ? V::load(base + idx * F + col) : V::zero();
+        const bool on = col_ok && ent[j] != -1 && !(a.debug & 1);
+        if constexpr (FAST) {
+          const unsigned off = __umul24((unsigned)ent[j] & 0x3fffffffu, row_bytes) + col_bytes;
+          const bool mat = a.Xe_mat && (ent[j] & 0x40000000);
+          hg_u4 q = {0u, 0u, 0u, 0u};
+          if (on && !mat) q = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+          if (a.Xe_mat) {  // wave-uniform: only graphs with materialised hyperedges pay for it
+            if (on && mat) q = __builtin_amdgcn_raw_buffer_load_b128(rm, off, 0, 0);
+          }
+          v[j].v = __builtin_bit_cast(float4, q);
+        } else {
+          const int64_t idx = ent[j] & 0x3fffffff;
+          const float *base = (a.Xe_mat && (ent[j] & 0x40000000)) ? a.Xe_mat : a.X;
+          v[j] = on ? V::load(base + idx * F + col) : V::zero();
+        }
       }
 #pragma unroll
       for (int j = 0; j < U; j++) {
-        if (ent[j] != -1) {
-          acc.add(v[j]);
-          if (ent[j] < 0) {  // last member of this slot
-            if (a.degE) acc.mul(sA[slot]);
-            if (a.W) acc.mul(sB[slot]);
-            acc.store(tile + slot * TW + lcol);
-            slot++;
-            acc = V::zero();
-          }
+        acc.add(v[j]);        // an idle step contributed zeros
+        if (ent[j] < -1) {    // bit 31 set and not the idle word: last member of this slot
+          if (a.degE) acc.mul(sA[slot]);
+          if (a.W) acc.mul(sB[slot]);
+          acc.store(tile + slot * TW + lcol);
+          slot++;
+          acc = V::zero();
         }
       }
     }
@@ -1190,6 +1216,7 @@ struct Tuning {
   int fused_persist = 0;
   int fused_ws = 0;
   int fused_packed = 1;
+  int fused_fast = 1;
   int fused_grid = 0;
   int fused_debug = 0;  // ablation bits for fused_panel_kernel (timing experiments only)
 };
@@ -1205,6 +1232,7 @@ static const Tuning &tuning() {
     if (const char *e = getenv("HG_FUSED_PERSIST")) x.fused_persist = atoi(e) != 0;
     if (const char *e = getenv("HG_FUSED_WS")) x.fused_ws = atoi(e) != 0;
     if (const char *e = getenv("HG_FUSED_PACKED")) x.fused_packed = atoi(e);
+    if (const char *e = getenv("HG_FUSED_FAST")) x.fused_fast = atoi(e) != 0;
     if (const char *e = getenv("HG_FUSED_GRID")) x.fused_grid = atoi(e);
     if (const char *e = getenv("HG_FUSED_DEBUG")) x.fused_debug = atoi(e);
     return x;
@@ -1308,10 +1336,21 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
                          (size_t)(2 * a.cap + a.rows_cap) * 4 + 16;
     FusedArgs ap = a;
     ap.debug = t.fused_debug;
+    if constexpr (VEC == 4) {
+      const bool fast = t.fused_fast && a.x_bytes > 0 && a.nrows_x < (1 << 24) && a.F < (1 << 22) &&
+                        (!a.Xe_mat || a.mat_bytes > 0);
+      if (fast) {
+        if (t.fused_u == 4)
+          hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 4, true>), grid, dim3(256), lds_p, stream, ap);
+        else
+          hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 8, true>), grid, dim3(256), lds_p, stream, ap);
+        return hipGetLastError();
+      }
+    }
     if (t.fused_u == 4)
-      hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 4>), grid, dim3(256), lds_p, stream, ap);
+      hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 4, false>), grid, dim3(256), lds_p, stream, ap);
     else
-      hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 8>), grid, dim3(256), lds_p, stream, ap);
+      hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 8, false>), grid, dim3(256), lds_p, stream, ap);
     return hipGetLastError();
   }
   if (t.fused_ws) {
