@@ -130,9 +130,8 @@ void fused_caps(const hg_plan *p, int32_t F, bool vec4, bool dma, int32_t &cap, 
     mem_cap = std::max(64, std::min(2048, p->opts.fused_stage_bytes / row_bytes / 64 * 64));
     cap = std::max(16, mem_cap / 2);
   } else {
-    int c = std::max(16, std::min(256, p->opts.fused_tile_bytes / row_bytes));
-    cap = 16;
-    while (cap * 2 <= c) cap *= 2;
+    const int c = std::max(16, std::min(256, p->opts.fused_tile_bytes / row_bytes));
+    cap = c / 16 * 16;  // whole multiples of 16 slots
     mem_cap = cap * 4;
   }
 }
