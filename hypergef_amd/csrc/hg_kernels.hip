@@ -1217,6 +1217,7 @@ struct Tuning {
   int fused_ws = 0;
   int fused_packed = 1;
   int fused_fast = 1;
+  int fused_coltile = 1;
   int fused_grid = 0;
   int fused_debug = 0;  // ablation bits for fused_panel_kernel (timing experiments only)
 };
@@ -1233,6 +1234,7 @@ static const Tuning &tuning() {
     if (const char *e = getenv("HG_FUSED_WS")) x.fused_ws = atoi(e) != 0;
     if (const char *e = getenv("HG_FUSED_PACKED")) x.fused_packed = atoi(e);
     if (const char *e = getenv("HG_FUSED_FAST")) x.fused_fast = atoi(e) != 0;
+    if (const char *e = getenv("HG_FUSED_COLTILE")) x.fused_coltile = atoi(e) != 0;
     if (const char *e = getenv("HG_FUSED_GRID")) x.fused_grid = atoi(e);
     if (const char *e = getenv("HG_FUSED_DEBUG")) x.fused_debug = atoi(e);
     return x;
@@ -1393,9 +1395,10 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
   return hipGetLastError();
 }
 
+int fused_tile_row_floats(int F, bool vec4);
+
 hipError_t launch_fused(const FusedArgs &a, bool vec4, hipStream_t stream) {
-  const int lanes = vec4 ? a.F / 4 : a.F;
-  const int lpr = std::min(64, next_pow2(std::max(lanes, 1)));
+  const int lpr = fused_tile_row_floats(a.F, vec4) / (vec4 ? 4 : 1);
 #define HG_CASE(L) \
   case L:          \
     return vec4 ? launch_fused_t<L, 4>(a, stream) : launch_fused_t<L, 1>(a, stream);
@@ -1424,7 +1427,11 @@ hipError_t read_stamps(unsigned long long *out, bool reset) {
 }
 
 // floats per LDS tile row for feature width F (what launch_fused will use)
+// Wide rows (F a multiple of 32 floats, above 32) are cut into 128-byte column tiles, one
+// workgroup per (panel, tile): every workgroup then has the F = 32 shape -- 8 lanes per row,
+// 32 row groups, 128 slots in a 16 KB tile -- instead of a few fat row groups and tiny panels.
 int fused_tile_row_floats(int F, bool vec4) {
+  if (vec4 && tuning().fused_coltile && F > 32 && F % 32 == 0) return 32;
   const int lanes = vec4 ? F / 4 : F;
   return std::min(64, next_pow2(std::max(lanes, 1))) * (vec4 ? 4 : 1);
 }
