@@ -245,6 +245,11 @@ void pack_records(FusedSched &f, int32_t ng) {
     FRec rt;
     rt.off = (int64_t)f.rec.size();
     rt.len = words;
+    rt.off_prow = off_prow;
+    rt.off_eid = off_eid;
+    rt.nrows = pn.nrows;
+    rt.nslots = pn.nslots;
+    rt.pad = 0;
     f.rec_tab.push_back(rt);
     f.max_rec_words = std::max(f.max_rec_words, words);
     f.stream_entries += (int64_t)steps * ng;

@@ -20,6 +20,7 @@ template <> struct Vec<1> {
   __device__ __forceinline__ static Vec zero() { return Vec{0.f}; }
   __device__ __forceinline__ static Vec load(const float *p) { return Vec{*p}; }
   __device__ __forceinline__ void store(float *p) const { *p = x; }
+  __device__ __forceinline__ void store_nt(float *p) const { __builtin_nontemporal_store(x, p); }
   __device__ __forceinline__ void add(const Vec &o) { x += o.x; }
   __device__ __forceinline__ void mul(float s) { x *= s; }
   __device__ __forceinline__ void xor_reduce(int off) { x += __shfl_xor(x, off, 64); }
@@ -31,6 +32,10 @@ template <> struct Vec<4> {
     return Vec{*reinterpret_cast<const float4 *>(p)};
   }
   __device__ __forceinline__ void store(float *p) const { *reinterpret_cast<float4 *>(p) = v; }
+  __device__ __forceinline__ void store_nt(float *p) const {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(f4{v.x, v.y, v.z, v.w}, reinterpret_cast<f4 *>(p));
+  }
   __device__ __forceinline__ void add(const Vec &o) {
     v.x += o.v.x; v.y += o.v.y; v.z += o.v.z; v.w += o.v.w;
   }
@@ -515,26 +520,24 @@ __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
   // records are padded to whole 16-byte units: one dwordx4 per lane copies 4 KB per pass
   for (int i = tid; i < (rt.len >> 2); i += BS)
     reinterpret_cast<hg_i4 *>(rec)[i] = reinterpret_cast<const hg_i4 *>(grec)[i];
+  // The scale gathers start from the ids in global memory, in the same round trip as the
+  // record copy (the descriptor says where they are), not after it.
+  if (a.degE || a.W)
+    for (int i = tid; i < rt.nslots; i += BS) {
+      const int e = grec[rt.off_eid + i];  // -1: materialised row, already scaled
+      sA[i] = (a.degE && e >= 0) ? a.degE[e] : 1.f;
+      sB[i] = (a.W && e >= 0) ? a.W[e] : 1.f;
+    }
+  if (a.degV)
+    for (int i = tid; i < rt.nrows; i += BS) sdeg[i] = a.degV[grec[rt.off_prow + i]];
   __syncthreads();
   if (a.debug & 16) return;  // ablation (experiments): record copy only
-  const int steps = rec[0], nrows = rec[1], nslots = rec[2];
+  const int steps = rec[0], nrows = rec[1];
   const int32_t *gbase = rec + rec[4];
   const int32_t *stream = rec + rec[5];
   const int32_t *pend = rec + rec[6];
   const int32_t *prow = rec + rec[7];
-  const int32_t *eid = rec + rec[8];
   const uint16_t *pvs = reinterpret_cast<const uint16_t *>(rec + rec[9]);
-  if (a.degE || a.W || a.degV) {
-    if (a.degE || a.W)
-      for (int i = tid; i < nslots; i += BS) {
-        const int e = eid[i];  // -1: materialised row, already scaled
-        sA[i] = (a.degE && e >= 0) ? a.degE[e] : 1.f;
-        sB[i] = (a.W && e >= 0) ? a.W[e] : 1.f;
-      }
-    if (a.degV)
-      for (int i = tid; i < nrows; i += BS) sdeg[i] = a.degV[prow[i]];
-    __syncthreads();
-  }
 
   const int g = tid / LPR;
   if (!(a.debug & 4)) {  // ---- hop 1
@@ -592,7 +595,10 @@ __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
       const int pb = r ? pend[r - 1] : 0, pe = pend[r];
       for (int p = pb; p < pe; p++) acc.add(V::load(tile + (int)pvs[p] * TW + lcol));
       if (a.degV && pe > pb) acc.mul(sdeg[r]);
-      if (col_ok && !(a.debug & 2)) acc.store(a.Y + (int64_t)prow[r] * F + col);
+      if (col_ok && !(a.debug & 2)) {
+        if (a.debug & 64) acc.store_nt(a.Y + (int64_t)prow[r] * F + col);
+        else acc.store(a.Y + (int64_t)prow[r] * F + col);
+      }
     }
   }
 }
@@ -1217,7 +1223,7 @@ struct Tuning {
   int fused_ws = 0;
   int fused_packed = 1;
   int fused_fast = 1;
-  int fused_coltile = 1;
+  int fused_coltile = 0;
   int fused_grid = 0;
   int fused_debug = 0;  // ablation bits for fused_panel_kernel (timing experiments only)
 };
