@@ -24,7 +24,7 @@ VARIANTS = {"auto": HG_VARIANT_AUTO, "pull": HG_VARIANT_PULL, "push_atomic": HG_
 SYMBOLS = (
     "hg_version", "hg_last_error", "hg_status_string", "hg_balance_schedule", "hg_mtx_read", "hg_free",
     "hg_plan_create_host", "hg_plan_create_device", "hg_plan_destroy", "hg_plan_get_info",
-    "hg_plan_get_vertex_csr", "hg_plan_get_vertex_csr_device", "hg_plan_get_schedule", "hg_plan_prepare", "hg_plan_auto_variant",
+    "hg_plan_get_vertex_csr", "hg_plan_get_vertex_csr_device", "hg_plan_get_schedule", "hg_plan_prepare", "hg_plan_auto_variant", "hg_plan_bind_scales",
     "hg_plan_workspace_bytes",
     "hg_aggr_fused_f32", "hg_gather_rows_f32", "hg_aggr_push_groups_f32", "hg_gather_max_f32",
     "hg_scatter_record_f32",
@@ -114,6 +114,8 @@ def lib():
     L.hg_plan_get_schedule.argtypes = [vp, i32, vp, vp, vp]
     L.hg_plan_prepare.restype = ctypes.c_int
     L.hg_plan_prepare.argtypes = [vp, i32, ctypes.POINTER(FusedInfo)]
+    L.hg_plan_bind_scales.restype = ctypes.c_int
+    L.hg_plan_bind_scales.argtypes = [vp, i32, vp, vp, vp, vp]
     L.hg_plan_auto_variant.restype = ctypes.c_int
     L.hg_plan_auto_variant.argtypes = [vp, i32]
     L.hg_plan_workspace_bytes.restype = sz

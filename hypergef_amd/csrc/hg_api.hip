@@ -106,6 +106,7 @@ int fused_upload(hg::FusedSched &f, int64_t &bytes) {
   UP(hub_vid, d_hub_vid);
   UP(rec, d_rec);
   UP(rec_tab, d_rec_tab);
+  UP(eid_all, d_eid_all);
 #undef UP
   if ((rc = sched_upload(f.mat_sched, bytes)) != HG_OK) return rc;
   return sched_upload(f.hub_sched, bytes);
@@ -113,7 +114,8 @@ int fused_upload(hg::FusedSched &f, int64_t &bytes) {
 
 void fused_free(hg::FusedSched &f) {
   void *ptrs[] = {f.d_panels, f.d_soff, f.d_pmem, f.d_slot_eid, f.d_prow, f.d_pend, f.d_pvs, f.d_mat_ptr,
-                  f.d_mat_ind, f.d_mat_eid, f.d_hub_ptr, f.d_hub_ind, f.d_hub_vid, f.d_rec, f.d_rec_tab};
+                  f.d_mat_ind, f.d_mat_eid, f.d_hub_ptr, f.d_hub_ind, f.d_hub_vid, f.d_rec, f.d_rec_tab,
+                  f.d_eid_all, f.d_bsA, f.d_bsB, f.d_bsD};
   for (void *q : ptrs)
     if (q) (void)hipFree(q);
   sched_free(f.mat_sched);
@@ -429,6 +431,32 @@ int hg_plan_get_schedule(const hg_plan *p, int32_t hop, int32_t *panels, int32_t
   return HG_OK;
 }
 
+int hg_plan_bind_scales(const hg_plan *cp, int32_t F, const float *degE, const float *degV,
+                        const float *W, hg_stream_t stream) {
+  if (!cp || F <= 0 || (cp->opts.flags & HG_PLAN_HOST_ONLY)) {
+    hg::set_error("hg_plan_bind_scales: bad argument or host-only plan");
+    return HG_ERR_INVALID;
+  }
+  const hg::FusedSched *cf = nullptr;
+  int rc = get_fused(cp, F, F % 4 == 0, hg::fused_use_dma(), &cf);
+  if (rc != HG_OK) return rc;
+  hg::FusedSched *f = const_cast<hg::FusedSched *>(cf);
+  std::lock_guard<std::mutex> lock(const_cast<hg_plan *>(cp)->fused_mu);
+  const size_t ns = f->eid_all.size(), nr = f->prow.size();
+  if (!f->d_bsA && ns > 0) {
+    HG_HIP(hipMalloc(reinterpret_cast<void **>(&f->d_bsA), ns * sizeof(float)));
+    HG_HIP(hipMalloc(reinterpret_cast<void **>(&f->d_bsB), ns * sizeof(float)));
+  }
+  if (!f->d_bsD && nr > 0) HG_HIP(hipMalloc(reinterpret_cast<void **>(&f->d_bsD), nr * sizeof(float)));
+  hipError_t e = hg::launch_bind_scales((int64_t)ns, f->d_eid_all, degE, W, f->d_bsA, f->d_bsB, (int64_t)nr,
+                                        f->d_prow, degV, f->d_bsD, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return hip_fail("bind_scales launch", e);
+  f->bound_degE = degE;
+  f->bound_W = W;
+  f->bound_degV = degV;
+  return HG_OK;
+}
+
 int hg_plan_auto_variant(const hg_plan *p, int32_t F) {
   if (!p || F <= 0) {
     hg::set_error("hg_plan_auto_variant: bad argument");
@@ -631,6 +659,11 @@ int hg_aggr_fused_f32(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
     a.x_bytes = xb < ((int64_t)1 << 31) ? (int32_t)xb : 0;
     a.mat_bytes = mb < ((int64_t)1 << 31) ? (int32_t)mb : 0;
     a.nrows_x = plan->N;
+    // scales pre-gathered into panel order, if the caller bound exactly these arrays
+    const bool bound = (degE || degV || W) && f->bound_degE == degE && f->bound_W == W && f->bound_degV == degV;
+    a.bsA = bound ? f->d_bsA : nullptr;
+    a.bsB = bound ? f->d_bsB : nullptr;
+    a.bsD = bound ? f->d_bsD : nullptr;
     hipError_t e = hg::launch_fused(a, vec4, s);
     if (e != hipSuccess) return hip_fail("fused_panel launch", e);
     return HG_OK;

@@ -192,6 +192,7 @@ void pack_records(FusedSched &f, int32_t ng) {
   f.ng = ng;
   f.rec.clear();
   f.rec_tab.clear();
+  f.eid_all.clear();
   f.max_rec_words = 0;
   f.stream_entries = 0;
   std::vector<int32_t> order, load, gslots, newid, stream;
@@ -249,7 +250,9 @@ void pack_records(FusedSched &f, int32_t ng) {
     rt.off_eid = off_eid;
     rt.nrows = pn.nrows;
     rt.nslots = pn.nslots;
-    rt.pad = 0;
+    rt.slot_base = (int32_t)f.eid_all.size();
+    rt.row_base = pn.r0;
+    f.eid_all.insert(f.eid_all.end(), eid.begin(), eid.end());
     f.rec_tab.push_back(rt);
     f.max_rec_words = std::max(f.max_rec_words, words);
     f.stream_entries += (int64_t)steps * ng;

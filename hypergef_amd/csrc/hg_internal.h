@@ -58,7 +58,8 @@ struct FRec {
   int64_t off;  // word offset of the panel's record
   int32_t len;  // record length in words
   int32_t off_prow, off_eid;  // where the vertex ids / hyperedge ids sit inside the record
-  int32_t nrows, nslots, pad;
+  int32_t nrows, nslots;
+  int32_t slot_base, row_base;  // position of this panel's slots / rows in the bound scale arrays
 };
 
 struct FusedSched {
@@ -93,6 +94,12 @@ struct FusedSched {
   int64_t stream_entries = 0;  // steps * ng summed over panels (incl. idle steps)
   int32_t *d_rec = nullptr;
   FRec *d_rec_tab = nullptr;
+  // scales pre-gathered into panel order (hg_plan_bind_scales): per slot degE[e], W[e]
+  // (1 for materialised slots), per panel row degV[v]
+  std::vector<int32_t> eid_all;  // hyperedge id of every slot, record order
+  int32_t *d_eid_all = nullptr;
+  float *d_bsA = nullptr, *d_bsB = nullptr, *d_bsD = nullptr;
+  const float *bound_degE = nullptr, *bound_W = nullptr, *bound_degV = nullptr;
 };
 
 struct Opts {

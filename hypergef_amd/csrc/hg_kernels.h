@@ -45,6 +45,7 @@ struct FusedArgs {
   int32_t x_bytes;        // byte size of X if it fits a buffer descriptor (< 2 GiB), else 0
   int32_t mat_bytes;      // same for the materialised table
   int32_t nrows_x;        // rows of X
+  const float *bsA, *bsB, *bsD;  // bound scales in panel order (or null: gather from degE/W/degV)
   int32_t dma;  // 1: LDS-DMA kernel, 0: register-staged kernel
   int32_t debug = 0;  // ablation bits (experiments only)
 };
@@ -65,6 +66,9 @@ int fused_tile_row_floats(int F, bool vec4);
 bool fused_use_dma();
 hipError_t read_stamps(unsigned long long *out, bool reset);
 hipError_t launch_push(const PushArgs &a, hipStream_t stream);
+hipError_t launch_bind_scales(int64_t nslots, const int32_t *eid_all, const float *degE, const float *W,
+                              float *bsA, float *bsB, int64_t nrows, const int32_t *prow, const float *degV,
+                              float *bsD, hipStream_t stream);
 hipError_t launch_gather_max(int32_t M, int32_t F, const int32_t *ptr, const int32_t *ind, const float *X,
                              const float *degE, const float *W, float *Xe, int32_t *record,
                              hipStream_t stream);

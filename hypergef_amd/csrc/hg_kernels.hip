@@ -524,12 +524,18 @@ __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
   // record copy (the descriptor says where they are), not after it.
   if (a.degE || a.W)
     for (int i = tid; i < rt.nslots; i += BS) {
-      const int e = grec[rt.off_eid + i];  // -1: materialised row, already scaled
-      sA[i] = (a.degE && e >= 0) ? a.degE[e] : 1.f;
-      sB[i] = (a.W && e >= 0) ? a.W[e] : 1.f;
+      if (a.bsA) {  // bound: one coalesced read instead of a scattered 4-byte gather per slot
+        sA[i] = a.bsA[rt.slot_base + i];
+        sB[i] = a.bsB[rt.slot_base + i];
+      } else {
+        const int e = grec[rt.off_eid + i];  // -1: materialised row, already scaled
+        sA[i] = (a.degE && e >= 0) ? a.degE[e] : 1.f;
+        sB[i] = (a.W && e >= 0) ? a.W[e] : 1.f;
+      }
     }
   if (a.degV)
-    for (int i = tid; i < rt.nrows; i += BS) sdeg[i] = a.degV[grec[rt.off_prow + i]];
+    for (int i = tid; i < rt.nrows; i += BS)
+      sdeg[i] = a.bsD ? a.bsD[rt.row_base + i] : a.degV[grec[rt.off_prow + i]];
   __syncthreads();
   if (a.debug & 16) return;  // ablation (experiments): record copy only
   const int steps = rec[0], nrows = rec[1];
@@ -1505,6 +1511,30 @@ __global__ __launch_bounds__(256) void scatter_record_kernel(int32_t M, int32_t 
   const int32_t k = (int32_t)(t % F);
   const int64_t v = record[t];
   atomicAdd(Y + v * F + k, T[t] * (degV ? degV[v] : 1.f));
+}
+
+// hg_plan_bind_scales: degE[e], W[e] per slot and degV[v] per panel row, in record order.
+__global__ __launch_bounds__(256) void bind_scales_kernel(int64_t nslots, const int32_t *eid_all,
+                                                          const float *degE, const float *W, float *bsA,
+                                                          float *bsB, int64_t nrows, const int32_t *prow,
+                                                          const float *degV, float *bsD) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t < nslots) {
+    const int e = eid_all[t];  // -1: materialised row, already scaled
+    bsA[t] = (degE && e >= 0) ? degE[e] : 1.f;
+    bsB[t] = (W && e >= 0) ? W[e] : 1.f;
+  }
+  if (t < nrows) bsD[t] = degV ? degV[prow[t]] : 1.f;
+}
+
+hipError_t launch_bind_scales(int64_t nslots, const int32_t *eid_all, const float *degE, const float *W,
+                              float *bsA, float *bsB, int64_t nrows, const int32_t *prow, const float *degV,
+                              float *bsD, hipStream_t stream) {
+  const int64_t n = std::max(nslots, nrows);
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(bind_scales_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, nslots,
+                     eid_all, degE, W, bsA, bsB, nrows, prow, degV, bsD);
+  return hipGetLastError();
 }
 
 hipError_t launch_gather_max(int32_t M, int32_t F, const int32_t *ptr, const int32_t *ind, const float *X,

@@ -135,6 +135,8 @@ class Plan:
                 _check_feat(t, name, device=X.device)
                 if t.numel() != n:
                     raise ValueError("%s must have %d elements, got %d" % (name, n, t.numel()))
+        if (degE is not None or degV is not None or W is not None) and variant in ("auto", "fused"):
+            self._bind_scales(F, degE, degV, W, X.device)
         Y = out if out is not None else torch.empty((self.N, F), dtype=torch.float32, device=X.device)
         if workspace is None:
             workspace, nbytes = self._workspace(F, X.device)
@@ -145,6 +147,24 @@ class Plan:
                 self._h, F, _ptr(csrptr_t), _ptr(colind_t), _ptr(X), _ptr(degE), _ptr(degV), _ptr(W),
                 _ptr(Y), _ptr(workspace), nbytes, _lib.VARIANTS[variant], _stream_handle(X.device)))
         return Y
+
+    def _bind_scales(self, F, degE, degV, W, device):
+        """Degree / weight vectors are graph constants: pre-gather them into the fused
+        schedule's panel order once (hg_plan_bind_scales) and again only when a tensor is
+        replaced or modified in place (data_ptr / torch version counter)."""
+        if not hasattr(self, "_bound"):
+            self._bound, self._auto = {}, {}
+        if F not in self._auto:
+            self._auto[F] = self.auto_variant(F)
+        if self._auto[F] != "fused":
+            return
+        key = tuple(None if t is None else (t.data_ptr(), t._version) for t in (degE, degV, W))
+        if self._bound.get(F, (None,))[0] == key:
+            return
+        with torch.cuda.device(device):
+            _lib.check(_lib.lib().hg_plan_bind_scales(self._h, F, _ptr(degE), _ptr(degV), _ptr(W),
+                                                      _stream_handle(device)))
+        self._bound[F] = (key, degE, degV, W)  # keep the tensors (and so their addresses) alive
 
     def gather_rows(self, hop, csrptr_t, colind_t, src, scaleA=None, scaleB=None):
         """One hop: hop 0 = H^T src (rows = hyperedges), hop 1 = H src."""

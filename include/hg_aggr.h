@@ -163,6 +163,14 @@ HG_API int hg_plan_get_vertex_csr_device(const hg_plan *plan, const int32_t **pt
  * this itself on first use of a width, but that first call allocates device
  * memory and so cannot be captured into a hipGraph.  info may be NULL. */
 HG_API int hg_plan_prepare(const hg_plan *plan, int32_t F, hg_fused_info *info);
+/* Optional: pre-gather the degree / weight vectors into the fused schedule's panel
+ * order for feature width F.  Later hg_aggr_fused_f32 calls (fused variant) that pass
+ * exactly these three pointers read the scales with coalesced loads instead of one
+ * scattered 4-byte gather per hyperedge slot.  Re-bind after changing the vectors'
+ * contents; passing other pointers simply bypasses the binding.  Allocates on the
+ * first call per width (not capturable); enqueues one small kernel on `stream`. */
+HG_API int hg_plan_bind_scales(const hg_plan *plan, int32_t F, const float *degE,
+                               const float *degV, const float *W, hg_stream_t stream);
 /* The variant HG_VARIANT_AUTO resolves to for feature width F (builds the
  * F-dependent schedule if the choice needs it); negative hg_status on error. */
 HG_API int hg_plan_auto_variant(const hg_plan *plan, int32_t F);

@@ -422,3 +422,35 @@ def test_hipgraph_capture_replay(hg, oracle):
         g.replay()
         torch.cuda.synchronize()
         assert np.array_equal(Y.cpu().numpy(), ref)
+
+
+def test_bound_scales_follow_tensor_changes(hg, oracle):
+    """hg_plan_bind_scales: same bits as the gather path, and an in-place change of a degree
+    vector (torch version counter) or a new tensor re-binds."""
+    from hypergef_amd.plan import Plan
+    inc = _make("cora")
+    F = 32
+    X, degE, degV, W, H_ptr, H_ind = _inputs(inc, F, oracle, seed=31, normal=True)
+    ptr, ind = _dev(inc.csrptr), _dev(inc.colind)
+    plan = Plan.from_tensors(inc.N, ptr, ind)
+    assert plan.auto_variant(F) == "fused"
+    x, dE, dV, w = _dev(X), _dev(degE.ravel()), _dev(degV.ravel()), _dev(W)
+    ref = oracle.hgnn_check(inc.N, inc.M, F, H_ptr, H_ind, inc.csrptr, inc.colind, X, degE, degV, W)
+    y_bound = plan.aggregate(ptr, ind, x, dE, dV, w)                       # binds
+    assert np.array_equal(y_bound.cpu().numpy(), ref)
+    y_gather = plan.aggregate(ptr, ind, x, dE, dV, w, variant="pull")      # never bound
+    assert torch.equal(y_bound, y_gather)
+    w.mul_(2.0)                                                            # in place: version bump
+    y2 = plan.aggregate(ptr, ind, x, dE, dV, w)
+    assert torch.equal(y2, y_bound * 2.0)
+    w2 = w.clone() * 0.5                                                   # new tensor, old values
+    assert torch.equal(plan.aggregate(ptr, ind, x, dE, dV, w2), y_bound)
+    # the C ABI ignores a binding made for other pointers
+    from hypergef_amd import _lib
+    from hypergef_amd.plan import _ptr, _stream_handle
+    ws = torch.empty(max(plan.workspace_bytes(F), 256), dtype=torch.uint8, device=DEV)
+    y3 = torch.empty_like(y_bound)
+    w3 = w2.clone()
+    _lib.check(_lib.lib().hg_aggr_fused_f32(plan._h, F, _ptr(ptr), _ptr(ind), _ptr(x), _ptr(dE), _ptr(dV), _ptr(w3),
+                                            _ptr(y3), _ptr(ws), ws.numel(), 3, _stream_handle(x.device)))
+    assert torch.equal(y3, y_bound)
