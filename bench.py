@@ -208,7 +208,7 @@ def main():
     resolved = plan.auto_variant(F) if args.variant == "auto" else args.variant
     launches = 2 if resolved == "pull" else 1
     dominant = {"pull": "gather_rows_kernel (hop 1 + hop 2 launches averaged)",
-                "fused": "fused_panel_kernel", "push_atomic": "push_groups_kernel"}[resolved]
+                "fused": "fused_packed_kernel", "push_atomic": "push_groups_kernel"}[resolved]
     balg = b_alg(inc.N, inc.M, inc.nnz, F, n_w)
     kern_avg_s = dev_s / (args.steps * launches)
     achieved = balg / launches / kern_avg_s / 1e9
@@ -252,7 +252,7 @@ def main():
             Y1 = torch.empty((base.N, F), dtype=torch.float32, device=dev)
             ws1 = torch.empty(max(pl1.workspace_bytes(F), 256), dtype=torch.uint8, device=dev)
             single = {}
-            for var in ("pull", "push_atomic"):
+            for var in ("fused", "pull", "push_atomic"):
                 def f():
                     pl1.aggregate(p1, i1, X1, out=Y1, workspace=ws1, variant=var)
                 for _ in range(20):
