@@ -508,7 +508,10 @@ __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
     const int cpx = a.npanels >> 3, rem = a.npanels & 7;
     b = x * cpx + (x < rem ? x : rem) + i;
   }
+  const bool stamp = (a.debug & 32) && (threadIdx.x & 63) == 0;
+  unsigned long long t0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
   const FRec rt = a.rec_tab[b];
+  HG_STAMP(0);
   const int32_t *grec = a.rec + rt.off;
 
   float *tile = reinterpret_cast<float *>(smem);        // [cap * TW]
@@ -536,7 +539,9 @@ __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
   if (a.degV)
     for (int i = tid; i < rt.nrows; i += BS)
       sdeg[i] = a.bsD ? a.bsD[rt.row_base + i] : a.degV[grec[rt.off_prow + i]];
+  HG_STAMP(1);
   __syncthreads();
+  HG_STAMP(2);
   if (a.debug & 16) return;  // ablation (experiments): record copy only
   const int steps = rec[0], nrows = rec[1];
   const int32_t *gbase = rec + rec[4];
@@ -592,7 +597,9 @@ __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
       }
     }
   }
+  HG_STAMP(3);
   __syncthreads();
+  HG_STAMP(4);
   if (!(a.debug & 8)) {  // ---- hop 2
     const int rpg = (nrows + NG - 1) / NG;
     const int r0 = min(g * rpg, nrows), r1 = min(r0 + rpg, nrows);
@@ -607,6 +614,7 @@ __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
       }
     }
   }
+  HG_STAMP(5);
 }
 
 __device__ __forceinline__ void dma_copy_dwords(const int32_t *src, int32_t *dst, int n, int lane);

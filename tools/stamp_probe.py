@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """Per-phase cycle shares of fused_panel_kernel (diagnostic build path: HG_FUSED_DEBUG=32)."""
 import ctypes, os, sys
-os.environ["HG_FUSED_PERSIST"] = "0"
-os.environ["HG_FUSED_DEBUG"] = "32"
+os.environ["HG_FUSED_DEBUG"] = os.environ.get("STAMP_DEBUG", "32")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
@@ -26,10 +25,11 @@ for _ in range(n):
     plan.aggregate(ptr, ind, X, out=Y, workspace=ws, variant="fused")
 torch.cuda.synchronize()
 L.hg_debug_read_stamps(buf, 1)
-names = ["descriptor", "issue+wait lists", "barrier 1", "hop 1 (gather+tile)", "barrier 2", "hop 2 (tile->Y)"]
+names = ["descriptor", "record copy (+scale reads)", "barrier 1", "hop 1 (gather+tile)", "barrier 2", "hop 2 (tile->Y)"]
 tot = sum(buf[i] for i in range(6))
 info = plan.prepare(F)
 waves = info["panels"] * 4 * n
+clk = 1e8  # s_memtime ticks at 100 MHz on this part
 for i, nm in enumerate(names):
-    print("%-22s %6.1f %%   %8.0f cycles/wave" % (nm, 100.0 * buf[i] / tot, buf[i] / waves))
-print("total cycles/wave %.0f" % (tot / waves))
+    print("%-28s %6.1f %%   %8.3f us/wave" % (nm, 100.0 * buf[i] / tot, buf[i] / waves / clk * 1e6))
+print("total us/wave %.3f" % (tot / waves / clk * 1e6))
