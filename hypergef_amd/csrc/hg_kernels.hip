@@ -697,6 +697,8 @@ __global__ __launch_bounds__(320) void fused_packed_ws_kernel(const FusedArgs a)
     int32_t *nxt = (it & 1) ? buf0 : buf1;
     const int steps = rec[0];
     if (steps < 0) break;  // same LDS word for every wave: uniform exit
+    const bool stamp = (a.debug & 32) && !loader && (threadIdx.x & 63) == 0;
+    unsigned long long t0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
     if (loader) {
       const int lane = tid - CT;
       const int len = start_load(nxt, lane);
@@ -747,7 +749,9 @@ __global__ __launch_bounds__(320) void fused_packed_ws_kernel(const FusedArgs a)
         }
       }
     }
+    HG_STAMP(1);
     __syncthreads();  // (M)
+    HG_STAMP(2);
     {  // ---- hop 2
       const int rpg = (nrows + NG - 1) / NG;
       const int r0 = min(g * rpg, nrows), r1 = min(r0 + rpg, nrows);
@@ -759,7 +763,9 @@ __global__ __launch_bounds__(320) void fused_packed_ws_kernel(const FusedArgs a)
         if (col_ok && !(a.debug & 2)) acc.store(a.Y + (int64_t)prow[r] * F + col);
       }
     }
+    HG_STAMP(3);
     __syncthreads();  // (X)
+    HG_STAMP(4);
   }
 }
 

@@ -25,7 +25,7 @@ for _ in range(n):
     plan.aggregate(ptr, ind, X, out=Y, workspace=ws, variant="fused")
 torch.cuda.synchronize()
 L.hg_debug_read_stamps(buf, 1)
-names = ["descriptor", "record copy (+scale reads)", "barrier 1", "hop 1 (gather+tile)", "barrier 2", "hop 2 (tile->Y)"]
+names = os.environ.get("STAMP_NAMES", "descriptor,record copy (+scale reads),barrier 1,hop 1 (gather+tile),barrier 2,hop 2 (tile->Y)").split(",")
 tot = sum(buf[i] for i in range(6))
 info = plan.prepare(F)
 waves = info["panels"] * 4 * n
