@@ -627,6 +627,13 @@ __device__ __forceinline__ void dma_copy_dwords(const int32_t *src, int32_t *dst
 // on the current buffer: descriptor, record and scale latencies are off the
 // compute waves' critical path, and because a wave's memory counter is its own,
 // the loader's loads never queue ahead of the compute waves' row gathers.
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the
+// vector-memory counter, which on CDNA4 counts stores: in a persistent loop that would
+// expose the full latency of the Y stores at every panel boundary.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int LPR, int VEC, int U>
 __global__ __launch_bounds__(320) void fused_packed_ws_kernel(const FusedArgs a) {
   constexpr int CT = 256;
@@ -702,9 +709,9 @@ __global__ __launch_bounds__(320) void fused_packed_ws_kernel(const FusedArgs a)
     if (loader) {
       const int lane = tid - CT;
       const int len = start_load(nxt, lane);
-      __syncthreads();  // (M)
+      lds_barrier();  // (M)
       finish_load(nxt, len, lane);
-      __syncthreads();  // (X)
+      lds_barrier();  // (X)
       continue;
     }
     const int gl = tid & (LPR - 1);
@@ -750,7 +757,7 @@ __global__ __launch_bounds__(320) void fused_packed_ws_kernel(const FusedArgs a)
       }
     }
     HG_STAMP(1);
-    __syncthreads();  // (M)
+    lds_barrier();  // (M)
     HG_STAMP(2);
     {  // ---- hop 2
       const int rpg = (nrows + NG - 1) / NG;
@@ -764,7 +771,7 @@ __global__ __launch_bounds__(320) void fused_packed_ws_kernel(const FusedArgs a)
       }
     }
     HG_STAMP(3);
-    __syncthreads();  // (X)
+    lds_barrier();  // (X): the Y stores stay in flight across it
     HG_STAMP(4);
   }
 }
