@@ -48,7 +48,6 @@ def parse():
     p.add_argument("--variant", default="auto", choices=["auto", "pull", "fused", "push_atomic"])
     p.add_argument("--t-big", type=int, default=0)
     p.add_argument("--tile-bytes", type=int, default=0)
-    p.add_argument("--stage-bytes", type=int, default=0)
     p.add_argument("--weighted", action="store_true", help="hgnnaggr (degE, degV, W) instead of H H^T X")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true", help="skip single-graph / all-reduce extras")
@@ -177,8 +176,7 @@ def main():
     X = torch.from_numpy(X_host).to(dev)
     opts = planmod.make_opts(short_max=args.short_max, panel_rows=args.panel_rows,
                              panel_nnz=args.panel_nnz, xcd_remap=not args.no_xcd_remap,
-                             t_big=args.t_big, fused_tile_bytes=args.tile_bytes,
-                             fused_stage_bytes=args.stage_bytes)
+                             t_big=args.t_big, fused_tile_bytes=args.tile_bytes)
     t0 = time.perf_counter()
     plan = planmod.Plan.from_tensors(inc.N, ptr, ind, opts)
     plan_s = time.perf_counter() - t0

@@ -41,7 +41,7 @@ class PlanOpts(ctypes.Structure):
     _fields_ = [("short_max", ctypes.c_int32), ("split_len", ctypes.c_int32),
                 ("panel_rows", ctypes.c_int32), ("panel_nnz", ctypes.c_int32),
                 ("flags", ctypes.c_int32), ("t_big", ctypes.c_int32),
-                ("fused_tile_bytes", ctypes.c_int32), ("fused_stage_bytes", ctypes.c_int32)]
+                ("fused_tile_bytes", ctypes.c_int32)]
 
 
 class FusedInfo(ctypes.Structure):

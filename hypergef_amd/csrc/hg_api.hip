@@ -37,10 +37,9 @@ int resolve_opts(const hg_plan_opts *in, hg::Opts &o) {
     o.flags = in->flags;
     if (in->t_big > 0) o.t_big = in->t_big;
     if (in->fused_tile_bytes > 0) o.fused_tile_bytes = in->fused_tile_bytes;
-    if (in->fused_stage_bytes > 0) o.fused_stage_bytes = in->fused_stage_bytes;
   }
   if (o.short_max > o.panel_nnz || o.split_len < o.short_max || o.panel_rows > 4096 ||
-      o.panel_nnz > 16384 || o.fused_tile_bytes > 65536 || o.fused_stage_bytes > 131072) {
+      o.panel_nnz > 16384 || o.fused_tile_bytes > 65536) {
     hg::set_error("hg_plan_opts: need short_max <= panel_nnz <= 16384, split_len >= short_max, panel_rows <= 4096, fused_tile_bytes <= 65536");
     return HG_ERR_INVALID;
   }
@@ -91,13 +90,7 @@ int plan_upload(hg_plan *p) {
 int fused_upload(hg::FusedSched &f, int64_t &bytes) {
   int rc;
 #define UP(v, d) if ((rc = upload(f.v, &f.d, bytes)) != HG_OK) return rc
-  UP(panels, d_panels);
-  UP(soff, d_soff);
-  UP(pmem, d_pmem);
-  UP(slot_eid, d_slot_eid);
   UP(prow, d_prow);
-  UP(pend, d_pend);
-  UP(pvs, d_pvs);
   UP(mat_ptr, d_mat_ptr);
   UP(mat_ind, d_mat_ind);
   UP(mat_eid, d_mat_eid);
@@ -113,7 +106,7 @@ int fused_upload(hg::FusedSched &f, int64_t &bytes) {
 }
 
 void fused_free(hg::FusedSched &f) {
-  void *ptrs[] = {f.d_panels, f.d_soff, f.d_pmem, f.d_slot_eid, f.d_prow, f.d_pend, f.d_pvs, f.d_mat_ptr,
+  void *ptrs[] = {f.d_prow, f.d_mat_ptr,
                   f.d_mat_ind, f.d_mat_eid, f.d_hub_ptr, f.d_hub_ind, f.d_hub_vid, f.d_rec, f.d_rec_tab,
                   f.d_eid_all, f.d_bsA, f.d_bsB, f.d_bsD};
   for (void *q : ptrs)
@@ -122,27 +115,20 @@ void fused_free(hg::FusedSched &f) {
   sched_free(f.hub_sched);
 }
 
-// Capacities of a fused panel for feature width F.  LDS-DMA kernel: the landing
-// zone holds mem_cap gathered rows (a multiple of 64 so that whole DMA
-// instructions fit), slots = mem_cap / 2.  Register-staged kernel: a tile of
-// `cap` rows, 4 entries per slot on average.
-void fused_caps(const hg_plan *p, int32_t F, bool vec4, bool dma, int32_t &cap, int32_t &mem_cap) {
+// Capacities of a fused panel for feature width F: `cap` hyperedge slots (rows of the
+// LDS tile, whole multiples of 16), four stream entries per slot on average.
+void fused_caps(const hg_plan *p, int32_t F, bool vec4, int32_t &cap, int32_t &mem_cap) {
   const int row_bytes = hg::fused_tile_row_floats(F, vec4) * 4;
-  if (dma) {
-    mem_cap = std::max(64, std::min(2048, p->opts.fused_stage_bytes / row_bytes / 64 * 64));
-    cap = std::max(16, mem_cap / 2);
-  } else {
-    const int c = std::max(16, std::min(256, p->opts.fused_tile_bytes / row_bytes));
-    cap = c / 16 * 16;  // whole multiples of 16 slots
-    mem_cap = cap * 4;
-  }
+  const int c = std::max(16, std::min(256, p->opts.fused_tile_bytes / row_bytes));
+  cap = c / 16 * 16;
+  mem_cap = cap * 4;
 }
 
 // The F-dependent part of the plan, built on first use (guarded by the plan's mutex).
-int get_fused(const hg_plan *cp, int32_t F, bool vec4, bool dma, const hg::FusedSched **out) {
+int get_fused(const hg_plan *cp, int32_t F, bool vec4, const hg::FusedSched **out) {
   hg_plan *p = const_cast<hg_plan *>(cp);
   int32_t cap, mem_cap;
-  fused_caps(p, F, vec4, dma, cap, mem_cap);
+  fused_caps(p, F, vec4, cap, mem_cap);
   const int32_t ng = 256 / (hg::fused_tile_row_floats(F, vec4) / (vec4 ? 4 : 1));  // lane groups per workgroup
   const int64_t key = ((int64_t)cap * 1000000 + mem_cap) * 1000 + ng;
   std::lock_guard<std::mutex> lock(p->fused_mu);
@@ -198,11 +184,11 @@ Carve carve(const hg_plan *p, int32_t F) {
 // citeseer / pubmed shapes 1.05-1.4x over the two-phase pull) and loses when nearly
 // everything has to be materialised anyway (power-law hubs).  First a free test on
 // the size histogram, then the built schedule.
-int pick_variant(const hg_plan *plan, int32_t F, bool vec4, bool dma, int32_t *variant,
+int pick_variant(const hg_plan *plan, int32_t F, bool vec4, int32_t *variant,
                  const hg::FusedSched **f) {
   *variant = HG_VARIANT_PULL;
   if (plan->small_nnz_frac >= 0.5) {
-    int rc = get_fused(plan, F, vec4, dma, f);
+    int rc = get_fused(plan, F, vec4, f);
     if (rc != HG_OK) return rc;
     if ((*f)->pmem_entries <= (int64_t)(2.6 * (double)plan->nnz) && (int64_t)(*f)->n_mat * 4 <= plan->M)
       *variant = HG_VARIANT_FUSED;
@@ -438,7 +424,7 @@ int hg_plan_bind_scales(const hg_plan *cp, int32_t F, const float *degE, const f
     return HG_ERR_INVALID;
   }
   const hg::FusedSched *cf = nullptr;
-  int rc = get_fused(cp, F, F % 4 == 0, hg::fused_use_dma(), &cf);
+  int rc = get_fused(cp, F, F % 4 == 0, &cf);
   if (rc != HG_OK) return rc;
   hg::FusedSched *f = const_cast<hg::FusedSched *>(cf);
   std::lock_guard<std::mutex> lock(const_cast<hg_plan *>(cp)->fused_mu);
@@ -464,7 +450,7 @@ int hg_plan_auto_variant(const hg_plan *p, int32_t F) {
   }
   int32_t variant = HG_VARIANT_PULL;
   const hg::FusedSched *f = nullptr;
-  int rc = pick_variant(p, F, F % 4 == 0, hg::fused_use_dma(), &variant, &f);
+  int rc = pick_variant(p, F, F % 4 == 0, &variant, &f);
   return rc != HG_OK ? rc : variant;
 }
 
@@ -474,7 +460,7 @@ int hg_plan_prepare(const hg_plan *p, int32_t F, hg_fused_info *info) {
     return HG_ERR_INVALID;
   }
   const hg::FusedSched *f = nullptr;
-  int rc = get_fused(p, F, F % 4 == 0, hg::fused_use_dma(), &f);
+  int rc = get_fused(p, F, F % 4 == 0, &f);
   if (rc != HG_OK) return rc;
   if (info) {
     info->cap = f->cap;
@@ -608,13 +594,12 @@ int hg_aggr_fused_f32(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
   char *ws = static_cast<char *>(workspace);
   float *Xe = reinterpret_cast<float *>(ws + c.xe);
   const bool vec4 = (F % 4 == 0) && aligned16(X) && aligned16(Y) && aligned16(Xe);
-  const bool dma = hg::fused_use_dma();
   const hg::FusedSched *f = nullptr;
   if (variant == HG_VARIANT_AUTO) {
-    if ((rc = pick_variant(plan, F, vec4, dma, &variant, &f)) != HG_OK) return rc;
+    if ((rc = pick_variant(plan, F, vec4, &variant, &f)) != HG_OK) return rc;
   }
   if (variant == HG_VARIANT_FUSED) {
-    if (!f && (rc = get_fused(plan, F, vec4, dma, &f)) != HG_OK) return rc;
+    if (!f && (rc = get_fused(plan, F, vec4, &f)) != HG_OK) return rc;
     // (a) materialised hyperedges (long ones, and those of hub vertices): Xe_mat rows
     if (f->n_mat > 0) {
       rc = run_sched(plan, f->mat_sched, F, f->d_mat_ptr, f->d_mat_ind, X, degE, W, f->d_mat_eid,
@@ -629,14 +614,7 @@ int hg_aggr_fused_f32(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
     }
     // (c) everything else: vertex panels with the hyperedge sums staged in LDS
     hg::FusedArgs a;
-    a.panels = f->d_panels;
     a.npanels = (int32_t)f->panels.size();
-    a.soff = f->d_soff;
-    a.pmem = f->d_pmem;
-    a.slot_eid = f->d_slot_eid;
-    a.prow = f->d_prow;
-    a.pend = f->d_pend;
-    a.pvs = f->d_pvs;
     a.X = X;
     a.Xe_mat = f->n_mat > 0 ? Xe : nullptr;  // null = no materialised rows: kernels skip that path
     a.degE = degE;
@@ -646,10 +624,7 @@ int hg_aggr_fused_f32(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
     a.F = F;
     a.cap = f->cap;
     a.rows_cap = f->rows_cap;
-    a.mem_cap = f->mem_cap;
-    a.vslot_cap = f->vslot_cap;
     a.xcd_remap = (plan->opts.flags & HG_PLAN_NO_XCD_REMAP) ? 0 : 1;
-    a.dma = dma ? 1 : 0;
     a.rec = f->d_rec;
     a.rec_tab = f->d_rec_tab;
     a.max_rec_words = f->max_rec_words;

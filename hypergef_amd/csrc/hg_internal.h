@@ -78,11 +78,8 @@ struct FusedSched {
   // (compact CSR over their materialised hyperedges)
   std::vector<int32_t> mat_ptr, mat_ind, mat_eid, hub_ptr, hub_ind, hub_vid;
   Sched mat_sched, hub_sched;
-  // device copies
-  FPanel *d_panels = nullptr;
-  int32_t *d_soff = nullptr, *d_pmem = nullptr, *d_slot_eid = nullptr;
-  int32_t *d_prow = nullptr, *d_pend = nullptr;
-  uint16_t *d_pvs = nullptr;
+  // device copies (the panel lists above stay on the host: the kernel reads the packed records)
+  int32_t *d_prow = nullptr;
   int32_t *d_mat_ptr = nullptr, *d_mat_ind = nullptr, *d_mat_eid = nullptr;
   int32_t *d_hub_ptr = nullptr, *d_hub_ind = nullptr, *d_hub_vid = nullptr;
   int64_t pmem_entries = 0;
@@ -109,8 +106,7 @@ struct Opts {
   int32_t panel_nnz = 1024;
   int32_t flags = 0;
   int32_t t_big = 8;           // fused: recompute hyperedges of at most this many members
-  int32_t fused_tile_bytes = 16384;  // fused (register-staged kernel): LDS tile budget -> slot capacity
-  int32_t fused_stage_bytes = 32768;  // fused (LDS-DMA kernel): LDS landing zone for gathered rows
+  int32_t fused_tile_bytes = 16384;  // fused: LDS tile budget -> hyperedge slots per panel
 };
 
 void set_error(const std::string &msg);

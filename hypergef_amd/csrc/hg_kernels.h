@@ -27,27 +27,22 @@ struct GatherArgs {
 };
 
 struct FusedArgs {
-  const FPanel *panels;
   int32_t npanels;
-  const int32_t *soff, *pmem, *slot_eid;
-  const int32_t *prow, *pend;
-  const uint16_t *pvs;
-  const float *X, *Xe_mat, *degE, *W, *degV;
-  float *Y;
-  int32_t F;
-  int32_t cap, rows_cap, mem_cap, vslot_cap;
-  int32_t xcd_remap;
-  const int32_t *rec;     // packed per-panel records
-  const FRec *rec_tab;    // per panel: record offset / length
+  const int32_t *rec;     // packed per-panel records (hg_fused.cpp, pack_records)
+  const FRec *rec_tab;    // per panel: record offset / length / list positions
   int32_t max_rec_words;  // LDS space for one record
   int32_t ng;             // lane groups the records were packed for
+  int32_t cap, rows_cap;  // LDS tile rows (hyperedge slots) and rows per panel
+  const float *X, *Xe_mat, *degE, *W, *degV;
+  const float *bsA, *bsB, *bsD;  // bound scales in panel order (or null: gather from degE/W/degV)
+  float *Y;
+  int32_t F;
+  int32_t xcd_remap;
   int32_t *counters;      // 8 x 16 ints of per-XCD-class work counters (persistent kernel)
   int32_t x_bytes;        // byte size of X if it fits a buffer descriptor (< 2 GiB), else 0
   int32_t mat_bytes;      // same for the materialised table
   int32_t nrows_x;        // rows of X
-  const float *bsA, *bsB, *bsD;  // bound scales in panel order (or null: gather from degE/W/degV)
-  int32_t dma;  // 1: LDS-DMA kernel, 0: register-staged kernel
-  int32_t debug = 0;  // ablation bits (experiments only)
+  int32_t debug = 0;      // ablation / stamp bits (experiments only)
 };
 
 struct PushArgs {
@@ -63,7 +58,6 @@ hipError_t launch_gather(const GatherArgs &a, int nfix, const Fixup *fixups, boo
                          hipStream_t stream);
 hipError_t launch_fused(const FusedArgs &a, bool vec4, hipStream_t stream);
 int fused_tile_row_floats(int F, bool vec4);
-bool fused_use_dma();
 hipError_t read_stamps(unsigned long long *out, bool reset);
 hipError_t launch_push(const PushArgs &a, hipStream_t stream);
 hipError_t launch_bind_scales(int64_t nslots, const int32_t *eid_all, const float *degE, const float *W,

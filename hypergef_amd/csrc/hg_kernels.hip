@@ -223,17 +223,6 @@ __global__ __launch_bounds__(256) void fixup_rows_kernel(const GatherArgs a, con
   acc.store(a.dst + drow * F + col);
 }
 
-// Fused V->E->V for one vertex panel, hyperedge sums staged in LDS.
-//  stage : the panel's slot offsets, member entries, (vertex,slot) incidences,
-//          row pointers and scales -> LDS (coalesced loads)
-//  hop 1 : every LPR-lane group walks a contiguous run of slots as one flat entry
-//          stream (U row gathers in flight; an entry with bit 31 set reads the
-//          materialised table instead of X), scales the finished sum by
-//          degE*W and writes it to its row of the LDS tile
-//  hop 2 : every group sums, for each of its vertices, the tile rows of the
-//          vertex's hyperedges in H-CSR order, scales by degV and stores Y.
-// Same arithmetic and order as the two-phase path (and the CPU reference), but
-// the hyperedge feature rows never leave the CU.
 // Diagnostic stamps (debug bit 32): lane 0 of every wave adds the cycles since
 // the previous stamp to a global counter per phase.  Never on in production.
 __device__ unsigned long long hg_stamps[8];
@@ -245,232 +234,6 @@ __device__ unsigned long long hg_stamps[8];
       t0 = t1;                                                             \
     }                                                                      \
   } while (0)
-
-template <int LPR, int VEC, int U, int BS>
-__global__ __launch_bounds__(BS) void fused_panel_kernel(const FusedArgs a) {
-  constexpr int NG = BS / LPR;
-  constexpr int TW = LPR * VEC;  // tile row stride in floats
-  using V = Vec<VEC>;
-  extern __shared__ int32_t smem[];
-  const int tid = threadIdx.x;
-  const int gl = tid & (LPR - 1);
-  const int lcol = gl * VEC;
-  const int col = blockIdx.y * TW + lcol;
-  const bool col_ok = col < a.F;
-  const int64_t F = a.F;
-  int b = blockIdx.x;
-  if (a.xcd_remap) {
-    const int x = b & 7, i = b >> 3;
-    const int cpx = a.npanels >> 3, rem = a.npanels & 7;
-    b = x * cpx + (x < rem ? x : rem) + i;
-  }
-  const bool stamp = (a.debug & 32) && (threadIdx.x & 63) == 0;
-  unsigned long long t0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
-  const FPanel pn = a.panels[b];
-  HG_STAMP(0);
-
-  float *tile = reinterpret_cast<float *>(smem);            // [cap * TW]
-  int32_t *soff = smem + a.cap * TW;                         // [cap + 1]
-  float *sA = reinterpret_cast<float *>(soff + a.cap + 1);   // [cap]
-  float *sB = sA + a.cap;                                    // [cap]
-  int32_t *spm = reinterpret_cast<int32_t *>(sB + a.cap);    // [mem_cap]
-  int32_t *sptr = spm + a.mem_cap;                           // [rows_cap + 1]
-  float *sdeg = reinterpret_cast<float *>(sptr + a.rows_cap + 1);  // [rows_cap]
-  int32_t *srow = reinterpret_cast<int32_t *>(sdeg + a.rows_cap);  // [rows_cap]
-  uint16_t *svs = reinterpret_cast<uint16_t *>(srow + a.rows_cap);  // [vslot_cap]
-
-  for (int i = tid; i <= pn.nslots; i += BS) soff[i] = a.soff[pn.sbase + i];
-  for (int i = tid; i < pn.npm; i += BS) spm[i] = a.pmem[pn.pm0 + i];
-  if (tid == 0) sptr[0] = 0;
-  for (int i = tid; i < pn.nrows; i += BS) {
-    sptr[i + 1] = a.pend[pn.r0 + i];
-    const int v = a.prow[pn.r0 + i];
-    srow[i] = v;
-    if (a.degV) sdeg[i] = a.degV[v];
-  }
-  for (int i = tid; i < pn.nvs; i += BS) svs[i] = a.pvs[pn.v0 + i];
-  if (a.degE || a.W) {
-    for (int i = tid; i < pn.nslots; i += BS) {
-      const int e = a.slot_eid[pn.eid0 + i];  // -1: materialised row, already scaled
-      sA[i] = (a.degE && e >= 0) ? a.degE[e] : 1.0f;
-      sB[i] = (a.W && e >= 0) ? a.W[e] : 1.0f;
-    }
-  }
-  HG_STAMP(1);
-  __syncthreads();
-  HG_STAMP(2);
-  if (a.debug & 16) return;  // ablation: descriptor + lists only
-
-  const int g = tid / LPR;
-  if (!(a.debug & 4)) {  // ---- hop 1: slots -> LDS tile
-    const int spg = (pn.nslots + NG - 1) / NG;
-    int k = min(g * spg, pn.nslots);
-    const int ke = min(k + spg, pn.nslots);
-    if (k < ke) {
-      auto flush = [&](int slot, V acc) {
-        if (a.degE) acc.mul(sA[slot]);
-        if (a.W) acc.mul(sB[slot]);
-        acc.store(tile + slot * TW + lcol);
-      };
-      int pos = soff[k];
-      const int stop = soff[ke];
-      int slot_end = soff[k + 1];
-      V acc = V::zero();
-      while (pos < stop) {
-        const int n = min(U, stop - pos);
-        V v[U];
-#pragma unroll
-        for (int j = 0; j < U; j++) {
-          const int ent = spm[pos + min(j, n - 1)];
-          const float *base = ent < 0 ? a.Xe_mat : a.X;
-          const int64_t idx = ent & 0x7fffffff;
-          v[j] = (col_ok && !(a.debug & 1)) ? V::load(base + idx * F + col) : V::zero();
-        }
-#pragma unroll
-        for (int j = 0; j < U; j++) {
-          if (j < n) {
-            while (slot_end <= pos + j) {
-              flush(k, acc);
-              acc = V::zero();
-              k++;
-              slot_end = soff[k + 1];
-            }
-            acc.add(v[j]);
-          }
-        }
-        pos += n;
-      }
-      flush(k, acc);  // every slot has at least one entry, so the last one is still open
-    }
-  }
-  HG_STAMP(3);
-  __syncthreads();
-  HG_STAMP(4);
-  if (!(a.debug & 8)) {  // ---- hop 2: vertices <- LDS tile
-    const int rpg = (pn.nrows + NG - 1) / NG;
-    const int r0 = min(g * rpg, pn.nrows), r1 = min(r0 + rpg, pn.nrows);
-    for (int r = r0; r < r1; r++) {
-      V acc = V::zero();
-      const int pb = sptr[r], pe = sptr[r + 1];
-      for (int p = pb; p < pe; p++) acc.add(V::load(tile + (int)svs[p] * TW + lcol));
-      if (a.degV && pe > pb) acc.mul(sdeg[r]);
-      if (col_ok && !(a.debug & 2)) acc.store(a.Y + (int64_t)srow[r] * F + col);
-    }
-  }
-  HG_STAMP(5);
-}
-
-// LDS-DMA form of the fused panel kernel.  Every member row of every slot of the
-// panel is gathered by `global_load_lds` (per-lane source address, LDS
-// destination = wave-uniform base + lane * 16 B, so one wave instruction lands
-// 64/LPR consecutive entries as consecutive rows of the landing zone) with no
-// VGPR staging: all of a panel's gathers are in flight at once instead of U per
-// lane.  The chain per workgroup is descriptor -> lists -> rows -> store.
-// Slot sums are then formed from LDS in entry order and written over the slot's
-// first entry row, which doubles as the hyperedge tile for hop 2.
-template <int LPR, int VEC>
-__global__ __launch_bounds__(256) void fused_dma_kernel(const FusedArgs a) {
-  constexpr int BS = 256;
-  constexpr int NG = BS / LPR;
-  constexpr int TW = LPR * VEC;   // row stride of the landing zone in floats
-  constexpr int EPI = 64 / LPR;   // entries per DMA wave instruction
-  using V = Vec<VEC>;
-  extern __shared__ int32_t smem[];
-  const int tid = threadIdx.x;
-  const int gl = tid & (LPR - 1);
-  const int lcol = gl * VEC;
-  const int col = blockIdx.y * TW + lcol;
-  const bool col_ok = col < a.F;
-  const int64_t F = a.F;
-  int b = blockIdx.x;
-  if (a.xcd_remap) {
-    const int x = b & 7, i = b >> 3;
-    const int cpx = a.npanels >> 3, rem = a.npanels & 7;
-    b = x * cpx + (x < rem ? x : rem) + i;
-  }
-  const FPanel pn = a.panels[b];
-
-  float *stage = reinterpret_cast<float *>(smem);             // [mem_cap * TW]
-  int32_t *soff = smem + a.mem_cap * TW;                       // [cap + 1]
-  float *sA = reinterpret_cast<float *>(soff + a.cap + 1);     // [cap]
-  float *sB = sA + a.cap;                                      // [cap]
-  int32_t *spm = reinterpret_cast<int32_t *>(sB + a.cap);      // [mem_cap]
-  int32_t *sptr = spm + a.mem_cap;                             // [rows_cap + 1]
-  float *sdeg = reinterpret_cast<float *>(sptr + a.rows_cap + 1);   // [rows_cap]
-  int32_t *srow = reinterpret_cast<int32_t *>(sdeg + a.rows_cap);   // [rows_cap]
-  int32_t *seid = srow + a.rows_cap;                           // [cap]
-  uint16_t *svs = reinterpret_cast<uint16_t *>(seid + a.cap);  // [vslot_cap]
-
-  for (int i = tid; i <= pn.nslots; i += BS) soff[i] = a.soff[pn.sbase + i];
-  for (int i = tid; i < pn.npm; i += BS) spm[i] = a.pmem[pn.pm0 + i];
-  if (tid == 0) sptr[0] = 0;
-  for (int i = tid; i < pn.nrows; i += BS) {
-    sptr[i + 1] = a.pend[pn.r0 + i];
-    srow[i] = a.prow[pn.r0 + i];
-  }
-  for (int i = tid; i < pn.nvs; i += BS) svs[i] = a.pvs[pn.v0 + i];
-  if (a.degE || a.W)
-    for (int i = tid; i < pn.nslots; i += BS) seid[i] = a.slot_eid[pn.eid0 + i];
-  __syncthreads();
-
-  // ---- all row gathers of the panel, straight into LDS
-  {
-    const int wave = tid >> 6, lane = tid & 63;
-    const int nchunks = (pn.npm + EPI - 1) / EPI;
-    for (int c = wave; c < nchunks; c += BS / 64) {
-      const int e = min(c * EPI + lane / LPR, pn.npm - 1);
-      const int ent = spm[e];
-      const float *base = ent < 0 ? a.Xe_mat : a.X;
-      const float *src = base + (int64_t)(ent & 0x7fffffff) * F + col;
-      float *dst = stage + (size_t)c * EPI * TW;  // hardware adds lane * VEC * 4 bytes
-      if (col_ok) {
-        // the size argument must be a literal (1, 2, 4, 12 or 16)
-        if constexpr (VEC == 4)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                           (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-        else
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                           (__attribute__((address_space(3))) void *)dst, 4, 0, 0);
-      }
-    }
-    // the scale gathers ride in the same round trip
-    if (a.degE || a.W)
-      for (int i = tid; i < pn.nslots; i += BS) {
-        const int e = seid[i];  // -1: materialised row, already scaled
-        sA[i] = (a.degE && e >= 0) ? a.degE[e] : 1.f;
-        sB[i] = (a.W && e >= 0) ? a.W[e] : 1.f;
-      }
-    if (a.degV)
-      for (int i = tid; i < pn.nrows; i += BS) sdeg[i] = a.degV[srow[i]];
-  }
-  __syncthreads();  // drains the DMA (vmcnt(0)) and publishes the scales
-
-  const int g = tid / LPR;
-  {  // ---- hop 1: slot sums, in entry order, written over the slot's first row
-    const int spg = (pn.nslots + NG - 1) / NG;
-    const int k0 = min(g * spg, pn.nslots), k1 = min(k0 + spg, pn.nslots);
-    for (int k = k0; k < k1; k++) {
-      const int pb = soff[k], pe = soff[k + 1];
-      V acc = V::zero();
-      for (int p = pb; p < pe; p++) acc.add(V::load(stage + p * TW + lcol));
-      if (a.degE) acc.mul(sA[k]);
-      if (a.W) acc.mul(sB[k]);
-      acc.store(stage + pb * TW + lcol);
-    }
-  }
-  __syncthreads();
-  {  // ---- hop 2: vertices <- slot rows
-    const int rpg = (pn.nrows + NG - 1) / NG;
-    const int r0 = min(g * rpg, pn.nrows), r1 = min(r0 + rpg, pn.nrows);
-    for (int r = r0; r < r1; r++) {
-      V acc = V::zero();
-      const int pb = sptr[r], pe = sptr[r + 1];
-      for (int p = pb; p < pe; p++) acc.add(V::load(stage + soff[svs[p]] * TW + lcol));
-      if (a.degV && pe > pb) acc.mul(sdeg[r]);
-      if (col_ok) acc.store(a.Y + (int64_t)srow[r] * F + col);
-    }
-  }
-}
 
 // Packed form of the fused panel kernel.  The plan hands every panel over as ONE
 // contiguous int32 record (hg_fused.cpp, pack_records): a single coalesced copy
@@ -617,7 +380,17 @@ __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
   HG_STAMP(5);
 }
 
-__device__ __forceinline__ void dma_copy_dwords(const int32_t *src, int32_t *dst, int n, int lane);
+// one wave copies n dwords global -> LDS with global_load_lds (64 dwords per instruction;
+// the LDS destination is wave-uniform base + lane * 4 B, the source address is per lane).
+// Sub-dword sizes are not used: a 2-byte global_load_lds does not land 2-byte granules.
+__device__ __forceinline__ void dma_copy_dwords(const int32_t *src, int32_t *dst, int n, int lane) {
+  for (int i0 = 0; i0 < n; i0 += 64) {
+    if (i0 + lane < n)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i0 + lane),
+                                       (__attribute__((address_space(3))) void *)(dst + i0), 4, 0, 0);
+  }
+}
+
 
 // Wave-specialised persistent form of fused_packed_kernel: 4 compute waves + 1
 // loader wave, two record buffers in LDS.  The loader wave draws the next panel of
@@ -776,427 +549,6 @@ __global__ __launch_bounds__(320) void fused_packed_ws_kernel(const FusedArgs a)
   }
 }
 
-// Persistent, software-pipelined form of fused_panel_kernel.  A workgroup walks a
-// strided sequence of its XCD's panels; while it gathers and sums panel i, the
-// lists of panel i+1 are already in flight (into registers, written to LDS when
-// panel i is done) and the descriptor of panel i+2 is being fetched, so the
-// descriptor -> lists -> rows dependency chain is paid once per workgroup, not
-// once per panel.  Arithmetic identical to fused_panel_kernel.
-template <int LPR, int VEC, int U>
-__global__ __launch_bounds__(256) void fused_persist_kernel(const FusedArgs a) {
-  constexpr int BS = 256;
-  constexpr int NG = BS / LPR;
-  constexpr int TW = LPR * VEC;
-  // register prefetch capacity per thread (cap <= 256, mem_cap <= 1024, vslot_cap <= 512)
-  constexpr int NK_SOFF = 2, NK_PM = 4, NK_ROW = 1, NK_VS = 2;
-  using V = Vec<VEC>;
-  extern __shared__ int32_t smem[];
-  const int tid = threadIdx.x;
-  const int gl = tid & (LPR - 1);
-  const int lcol = gl * VEC;
-  const int col = blockIdx.y * TW + lcol;
-  const bool col_ok = col < a.F;
-  const int64_t F = a.F;
-
-  // this workgroup's panel sequence: first, first + step, ... < last
-  int first, step, last;
-  {
-    const int w = blockIdx.x, G = gridDim.x;
-    if (a.xcd_remap && G >= 8) {
-      const int x = w & 7, j = w >> 3;
-      const int J = (G - x + 7) >> 3;  // workgroups of this XCD class
-      const int cpx = a.npanels >> 3, rem = a.npanels & 7;
-      const int start = x * cpx + (x < rem ? x : rem);
-      first = start + j;
-      step = J;
-      last = start + cpx + (x < rem ? 1 : 0);
-    } else {
-      first = w;
-      step = G;
-      last = a.npanels;
-    }
-  }
-  if (first >= last) return;
-
-  float *tile = reinterpret_cast<float *>(smem);            // [cap * TW]
-  int32_t *soff = smem + a.cap * TW;                         // [cap + 1]
-  float *sA = reinterpret_cast<float *>(soff + a.cap + 1);   // [cap]
-  float *sB = sA + a.cap;                                    // [cap]
-  int32_t *spm = reinterpret_cast<int32_t *>(sB + a.cap);    // [mem_cap]
-  int32_t *sptr = spm + a.mem_cap;                           // [rows_cap + 1]
-  float *sdeg = reinterpret_cast<float *>(sptr + a.rows_cap + 1);  // [rows_cap]
-  int32_t *srow = reinterpret_cast<int32_t *>(sdeg + a.rows_cap);  // [rows_cap]
-  uint16_t *svs = reinterpret_cast<uint16_t *>(srow + a.rows_cap);  // [vslot_cap]
-
-  const bool weighted = a.degE || a.W || a.degV;
-
-  struct Lists {  // one panel's lists, strided over the workgroup's threads
-    int32_t off[NK_SOFF], pm[NK_PM], pend[NK_ROW], row[NK_ROW], eid[NK_SOFF];
-    uint16_t vs[NK_VS];
-  };
-  auto fetch = [&](const FPanel &pn, Lists &L) {
-#pragma unroll
-    for (int k = 0; k < NK_SOFF; k++) {
-      const int i = tid + k * BS;
-      L.off[k] = i <= pn.nslots ? a.soff[pn.sbase + i] : 0;
-      L.eid[k] = (weighted && i < pn.nslots) ? a.slot_eid[pn.eid0 + i] : -1;
-    }
-#pragma unroll
-    for (int k = 0; k < NK_PM; k++) {
-      const int i = tid + k * BS;
-      L.pm[k] = i < pn.npm ? a.pmem[pn.pm0 + i] : 0;
-    }
-#pragma unroll
-    for (int k = 0; k < NK_ROW; k++) {
-      const int i = tid + k * BS;
-      L.pend[k] = i < pn.nrows ? a.pend[pn.r0 + i] : 0;
-      L.row[k] = i < pn.nrows ? a.prow[pn.r0 + i] : 0;
-    }
-#pragma unroll
-    for (int k = 0; k < NK_VS; k++) {
-      const int i = tid + k * BS;
-      L.vs[k] = i < pn.nvs ? a.pvs[pn.v0 + i] : (uint16_t)0;
-    }
-  };
-  // second-level gathers (scales), issued as soon as the ids are in registers
-  struct Scales {
-    float sa[NK_SOFF], sb[NK_SOFF], sd[NK_ROW];
-  };
-  auto fetch_scales = [&](const FPanel &pn, const Lists &L, Scales &S) {
-#pragma unroll
-    for (int k = 0; k < NK_SOFF; k++) {
-      const int i = tid + k * BS;
-      const int e = L.eid[k];
-      S.sa[k] = (a.degE && i < pn.nslots && e >= 0) ? a.degE[e] : 1.f;
-      S.sb[k] = (a.W && i < pn.nslots && e >= 0) ? a.W[e] : 1.f;
-    }
-#pragma unroll
-    for (int k = 0; k < NK_ROW; k++) {
-      const int i = tid + k * BS;
-      S.sd[k] = (a.degV && i < pn.nrows) ? a.degV[L.row[k]] : 1.f;
-    }
-  };
-  auto commit = [&](const FPanel &pn, const Lists &L, const Scales &S) {
-#pragma unroll
-    for (int k = 0; k < NK_SOFF; k++) {
-      const int i = tid + k * BS;
-      if (i <= pn.nslots) soff[i] = L.off[k];
-      if (weighted && i < pn.nslots) {
-        sA[i] = S.sa[k];
-        sB[i] = S.sb[k];
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < NK_PM; k++) {
-      const int i = tid + k * BS;
-      if (i < pn.npm) spm[i] = L.pm[k];
-    }
-    if (tid == 0) sptr[0] = 0;
-#pragma unroll
-    for (int k = 0; k < NK_ROW; k++) {
-      const int i = tid + k * BS;
-      if (i < pn.nrows) {
-        sptr[i + 1] = L.pend[k];
-        srow[i] = L.row[k];
-        if (weighted) sdeg[i] = S.sd[k];
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < NK_VS; k++) {
-      const int i = tid + k * BS;
-      if (i < pn.nvs) svs[i] = L.vs[k];
-    }
-  };
-
-  const int g = tid / LPR;
-  FPanel pn = a.panels[first];
-  Lists L;
-  Scales S;
-  fetch(pn, L);
-  if (weighted) fetch_scales(pn, L, S);
-  commit(pn, L, S);
-  int nxt = first + step;
-  FPanel pn1 = a.panels[min(nxt, a.npanels - 1)];
-  __syncthreads();
-
-  for (;; nxt += step) {
-    const bool has_next = nxt < last;
-    // descriptor two panels ahead, lists one panel ahead
-    const FPanel pn2 = a.panels[min(nxt + step, a.npanels - 1)];
-    if (has_next) fetch(pn1, L);
-
-    {  // ---- hop 1: slots -> LDS tile
-      const int spg = (pn.nslots + NG - 1) / NG;
-      int k = min(g * spg, pn.nslots);
-      const int ke = min(k + spg, pn.nslots);
-      if (k < ke) {
-        auto flush = [&](int slot, V acc) {
-          if (a.degE) acc.mul(sA[slot]);
-          if (a.W) acc.mul(sB[slot]);
-          acc.store(tile + slot * TW + lcol);
-        };
-        int pos = soff[k];
-        const int stop = soff[ke];
-        int slot_end = soff[k + 1];
-        V acc = V::zero();
-        while (pos < stop) {
-          const int n = min(U, stop - pos);
-          V v[U];
-#pragma unroll
-          for (int j = 0; j < U; j++) {
-            const int ent = spm[pos + min(j, n - 1)];
-            const float *base = ent < 0 ? a.Xe_mat : a.X;
-            const int64_t idx = ent & 0x7fffffff;
-            v[j] = col_ok ? V::load(base + idx * F + col) : V::zero();
-          }
-#pragma unroll
-          for (int j = 0; j < U; j++) {
-            if (j < n) {
-              while (slot_end <= pos + j) {
-                flush(k, acc);
-                acc = V::zero();
-                k++;
-                slot_end = soff[k + 1];
-              }
-              acc.add(v[j]);
-            }
-          }
-          pos += n;
-        }
-        flush(k, acc);
-      }
-    }
-    if (has_next && weighted) fetch_scales(pn1, L, S);  // ids have landed by now
-    __syncthreads();
-    {  // ---- hop 2: vertices <- LDS tile
-      const int rpg = (pn.nrows + NG - 1) / NG;
-      const int r0 = min(g * rpg, pn.nrows), r1 = min(r0 + rpg, pn.nrows);
-      for (int r = r0; r < r1; r++) {
-        V acc = V::zero();
-        const int pb = sptr[r], pe = sptr[r + 1];
-        for (int p = pb; p < pe; p++) acc.add(V::load(tile + (int)svs[p] * TW + lcol));
-        if (a.degV && pe > pb) acc.mul(sdeg[r]);
-        if (col_ok) acc.store(a.Y + (int64_t)srow[r] * F + col);
-      }
-    }
-    if (!has_next) break;
-    __syncthreads();  // everyone is done with this panel's lists and tile
-    commit(pn1, L, S);
-    pn = pn1;
-    pn1 = pn2;
-    __syncthreads();
-  }
-}
-
-// Wave-specialised persistent form: 4 compute waves + 1 loader wave per
-// workgroup, two list buffers in LDS.  While the compute waves gather and sum
-// panel i, the loader wave copies the lists of panel i+1 into the other buffer by
-// LDS-DMA (global_load_lds, no registers) and gathers its scales.  The loader's
-// memory counter is its own, so -- unlike a register prefetch issued by the
-// compute waves, whose row gathers would queue behind it -- the descriptor ->
-// lists latency is entirely off the compute waves' critical path.
-struct WsLists {
-  int32_t *soff;   // [cap + 1]
-  float *sA, *sB;  // [cap]
-  int32_t *seid;   // [cap]
-  int32_t *spm;    // [mem_cap]
-  int32_t *sptr;   // [rows_cap + 1]
-  float *sdeg;     // [rows_cap]
-  int32_t *srow;   // [rows_cap]
-  uint16_t *svs;   // [vslot_cap]
-  int32_t *hdr;    // [4]: nslots, nrows
-};
-
-__device__ __forceinline__ size_t ws_lists_dwords(const FusedArgs &a) {
-  return (size_t)(a.cap + 1) + 3 * (size_t)a.cap + a.mem_cap + (a.rows_cap + 1) + 2 * (size_t)a.rows_cap +
-         (a.vslot_cap + 1) / 2 + 4;
-}
-
-__device__ __forceinline__ WsLists ws_carve(int32_t *p, const FusedArgs &a) {
-  WsLists L;
-  L.soff = p;
-  L.sA = reinterpret_cast<float *>(L.soff + a.cap + 1);
-  L.sB = L.sA + a.cap;
-  L.seid = reinterpret_cast<int32_t *>(L.sB + a.cap);
-  L.spm = L.seid + a.cap;
-  L.sptr = L.spm + a.mem_cap;
-  L.sdeg = reinterpret_cast<float *>(L.sptr + a.rows_cap + 1);
-  L.srow = reinterpret_cast<int32_t *>(L.sdeg + a.rows_cap);
-  L.hdr = L.srow + a.rows_cap;
-  L.svs = reinterpret_cast<uint16_t *>(L.hdr + 4);
-  return L;
-}
-
-// one wave copies n dwords global -> LDS with global_load_lds (64 dwords per instruction)
-__device__ __forceinline__ void dma_copy_dwords(const int32_t *src, int32_t *dst, int n, int lane) {
-  for (int i0 = 0; i0 < n; i0 += 64) {
-    if (i0 + lane < n)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i0 + lane),
-                                       (__attribute__((address_space(3))) void *)(dst + i0), 4, 0, 0);
-  }
-}
-__device__ __forceinline__ void dma_copy_u16(const uint16_t *src, uint16_t *dst, int n, int lane) {
-  for (int i0 = 0; i0 < n; i0 += 64) {
-    if (i0 + lane < n)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i0 + lane),
-                                       (__attribute__((address_space(3))) void *)(dst + i0), 2, 0, 0);
-  }
-}
-
-template <int LPR, int VEC, int U>
-__global__ __launch_bounds__(320) void fused_ws_kernel(const FusedArgs a) {
-  constexpr int CT = 256;  // compute threads
-  constexpr int NG = CT / LPR;
-  constexpr int TW = LPR * VEC;
-  using V = Vec<VEC>;
-  extern __shared__ int32_t smem[];
-  const int tid = threadIdx.x;
-  const bool loader = tid >= CT;
-  const int64_t F = a.F;
-
-  int first, step, last;
-  {
-    const int w = blockIdx.x, G = gridDim.x;
-    if (a.xcd_remap && G >= 8) {
-      const int x = w & 7, j = w >> 3;
-      const int J = (G - x + 7) >> 3;
-      const int cpx = a.npanels >> 3, rem = a.npanels & 7;
-      const int start = x * cpx + (x < rem ? x : rem);
-      first = start + j;
-      step = J;
-      last = start + cpx + (x < rem ? 1 : 0);
-    } else {
-      first = w;
-      step = G;
-      last = a.npanels;
-    }
-  }
-  if (first >= last) return;
-
-  float *tile = reinterpret_cast<float *>(smem);  // [cap * TW]
-  const size_t ldw = ws_lists_dwords(a);
-  const WsLists B0 = ws_carve(smem + a.cap * TW, a);
-  const WsLists B1 = ws_carve(smem + a.cap * TW + ldw, a);
-  const bool weighted = a.degE || a.W || a.degV;
-
-  // loader wave: bring panel `idx` into buffer L
-  auto load_panel = [&](int idx, const WsLists &L, int lane) {
-    const FPanel pn = a.panels[idx];
-    dma_copy_dwords(a.soff + pn.sbase, L.soff, pn.nslots + 1, lane);
-    dma_copy_dwords(a.pmem + pn.pm0, L.spm, pn.npm, lane);
-    dma_copy_dwords(a.pend + pn.r0, L.sptr + 1, pn.nrows, lane);
-    dma_copy_dwords(a.prow + pn.r0, L.srow, pn.nrows, lane);
-    if (a.degE || a.W) dma_copy_dwords(a.slot_eid + pn.eid0, L.seid, pn.nslots, lane);
-    // 16-bit slot ids go through registers (sub-dword LDS-DMA is not relied upon)
-    for (int i = lane; i < pn.nvs; i += 64) L.svs[i] = a.pvs[pn.v0 + i];
-    if (lane == 0) {
-      L.sptr[0] = 0;
-      L.hdr[0] = pn.nslots;
-      L.hdr[1] = pn.nrows;
-    }
-    return pn;
-  };
-  // second level (needs the ids that just landed)
-  auto load_scales = [&](const FPanel &pn, const WsLists &L, int lane) {
-    if (a.degE || a.W)
-      for (int i = lane; i < pn.nslots; i += 64) {
-        const int e = L.seid[i];  // -1: materialised row, already scaled
-        L.sA[i] = (a.degE && e >= 0) ? a.degE[e] : 1.f;
-        L.sB[i] = (a.W && e >= 0) ? a.W[e] : 1.f;
-      }
-    if (a.degV)
-      for (int i = lane; i < pn.nrows; i += 64) L.sdeg[i] = a.degV[L.srow[i]];
-  };
-
-  if (loader) {
-    const int lane = tid - CT;
-    const FPanel pn = load_panel(first, B0, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (weighted) load_scales(pn, B0, lane);
-  }
-  __syncthreads();
-
-  int it = 0;
-  for (int cur = first; cur < last; cur += step, it++) {
-    const WsLists &L = (it & 1) ? B1 : B0;
-    const WsLists &Ln = (it & 1) ? B0 : B1;
-    const bool has_next = cur + step < last;
-    if (loader) {
-      const int lane = tid - CT;
-      FPanel pn{};
-      if (has_next) pn = load_panel(cur + step, Ln, lane);
-      __syncthreads();  // (M) do not hold the compute waves back
-      if (has_next) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (weighted) load_scales(pn, Ln, lane);
-      }
-      __syncthreads();  // (X) next buffer complete, this panel consumed
-      continue;
-    }
-    const int gl = tid & (LPR - 1);
-    const int lcol = gl * VEC;
-    const int col = blockIdx.y * TW + lcol;
-    const bool col_ok = col < a.F;
-    const int g = tid / LPR;
-    const int nslots = L.hdr[0], nrows = L.hdr[1];
-    {  // ---- hop 1: slots -> LDS tile
-      const int spg = (nslots + NG - 1) / NG;
-      int k = min(g * spg, nslots);
-      const int ke = min(k + spg, nslots);
-      if (k < ke) {
-        auto flush = [&](int slot, V acc) {
-          if (a.degE) acc.mul(L.sA[slot]);
-          if (a.W) acc.mul(L.sB[slot]);
-          acc.store(tile + slot * TW + lcol);
-        };
-        int pos = L.soff[k];
-        const int stop = L.soff[ke];
-        int slot_end = L.soff[k + 1];
-        V acc = V::zero();
-        while (pos < stop) {
-          const int n = min(U, stop - pos);
-          V v[U];
-#pragma unroll
-          for (int j = 0; j < U; j++) {
-            const bool on = col_ok && j < n;  // predicated off: no duplicate traffic
-            const int ent = on ? L.spm[pos + j] : 0;
-            const float *base = ent < 0 ? a.Xe_mat : a.X;
-            const int64_t idx = ent & 0x7fffffff;
-            v[j] = on ? V::load(base + idx * F + col) : V::zero();
-          }
-#pragma unroll
-          for (int j = 0; j < U; j++) {
-            if (j < n) {
-              while (slot_end <= pos + j) {
-                flush(k, acc);
-                acc = V::zero();
-                k++;
-                slot_end = L.soff[k + 1];
-              }
-              acc.add(v[j]);
-            }
-          }
-          pos += n;
-        }
-        flush(k, acc);
-      }
-    }
-    __syncthreads();  // (M)
-    {  // ---- hop 2: vertices <- LDS tile
-      const int rpg = (nrows + NG - 1) / NG;
-      const int r0 = min(g * rpg, nrows), r1 = min(r0 + rpg, nrows);
-      for (int r = r0; r < r1; r++) {
-        V acc = V::zero();
-        const int pb = L.sptr[r], pe = L.sptr[r + 1];
-        for (int p = pb; p < pe; p++) acc.add(V::load(tile + (int)L.svs[p] * TW + lcol));
-        if (a.degV && pe > pb) acc.mul(L.sdeg[r]);
-        if (col_ok) acc.store(a.Y + (int64_t)L.srow[r] * F + col);
-      }
-    }
-    __syncthreads();  // (X)
-  }
-}
-
 // The reference's register-fused scheme on wave64: LPR lanes = LPR feature
 // columns of one task, 64/LPR tasks per wave.  Gather-sum the read partition,
 // scale by degE*W, scatter acc*degV[v] to the write partition with hardware
@@ -1240,32 +592,25 @@ static inline int next_pow2(int x) {
   return p;
 }
 
+// Experiment knobs, read once from the environment.  Defaults are the measured best
+// (profiles/r01_fused_experiments.md); nothing here changes results.
 struct Tuning {
-  int unroll = 4;
-  int pipe = 0;
-  int fused_bs = 256;
-  int fused_u = 8;
-  int fused_dma = 0;
-  int fused_persist = 0;
-  int fused_ws = 0;
-  int fused_packed = 1;
-  int fused_fast = 1;
-  int fused_coltile = 0;
-  int fused_grid = 0;
-  int fused_debug = 0;  // ablation bits for fused_panel_kernel (timing experiments only)
+  int unroll = 4;        // HG_UNROLL = 4|8      : row loads in flight per lane, pull kernel
+  int pipe = 0;          // HG_PIPE = 0|1        : two batches in flight, pull kernel
+  int fused_u = 8;       // HG_FUSED_U = 4|8     : row loads in flight per lane, fused kernel
+  int fused_persist = 0; // HG_FUSED_PERSIST=1   : persistent kernel with a loader wave
+  int fused_fast = 1;    // HG_FUSED_FAST=0      : global loads instead of buffer loads
+  int fused_coltile = 0; // HG_FUSED_COLTILE=1   : 128-byte column tiles for wide rows
+  int fused_grid = 0;    // HG_FUSED_GRID=n      : workgroups of the persistent kernel
+  int fused_debug = 0;   // HG_FUSED_DEBUG=bits  : ablation / stamp switches (timing only)
 };
-// Experiment knobs (HG_UNROLL = 4|8, HG_PIPE = 0|1), read once.
 static const Tuning &tuning() {
   static const Tuning t = [] {
     Tuning x;
     if (const char *e = getenv("HG_UNROLL")) x.unroll = atoi(e) == 8 ? 8 : 4;
     if (const char *e = getenv("HG_PIPE")) x.pipe = atoi(e) != 0;
-    if (const char *e = getenv("HG_FUSED_BS")) x.fused_bs = atoi(e);
-    if (const char *e = getenv("HG_FUSED_U")) x.fused_u = atoi(e);
-    if (const char *e = getenv("HG_FUSED_DMA")) x.fused_dma = atoi(e) != 0;
+    if (const char *e = getenv("HG_FUSED_U")) x.fused_u = atoi(e) == 4 ? 4 : 8;
     if (const char *e = getenv("HG_FUSED_PERSIST")) x.fused_persist = atoi(e) != 0;
-    if (const char *e = getenv("HG_FUSED_WS")) x.fused_ws = atoi(e) != 0;
-    if (const char *e = getenv("HG_FUSED_PACKED")) x.fused_packed = atoi(e);
     if (const char *e = getenv("HG_FUSED_FAST")) x.fused_fast = atoi(e) != 0;
     if (const char *e = getenv("HG_FUSED_COLTILE")) x.fused_coltile = atoi(e) != 0;
     if (const char *e = getenv("HG_FUSED_GRID")) x.fused_grid = atoi(e);
@@ -1327,29 +672,22 @@ hipError_t launch_gather(const GatherArgs &a, int nfix, const Fixup *fixups, boo
 template <int LPR, int VEC>
 static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
   if (a.npanels == 0) return hipSuccess;
+  if (a.ng != 256 / LPR) return hipErrorInvalidValue;  // records were packed for another lane layout
   constexpr int TW = LPR * VEC;
   const int col_tiles = (a.F + TW - 1) / TW;
-  const size_t lds = (size_t)a.cap * TW * 4 + (size_t)(a.cap + 1 + 2 * a.cap + a.mem_cap + a.rows_cap + 1 + 2 * a.rows_cap) * 4 +
-                     (size_t)a.vslot_cap * 2 + 16;
-  const dim3 grid(a.npanels, col_tiles);
   const Tuning &t = tuning();
-  if (a.dma) {
-    const size_t lds_dma = (size_t)a.mem_cap * TW * 4 +
-                           (size_t)(a.cap + 1 + 2 * a.cap + a.mem_cap + a.rows_cap + 1 + 2 * a.rows_cap + a.cap) * 4 +
-                           (size_t)a.vslot_cap * 2 + 16;
-    hipLaunchKernelGGL((fused_dma_kernel<LPR, VEC>), grid, dim3(256), lds_dma, stream, a);
-    return hipGetLastError();
-  }
-  static int num_cu = 0;
-  if (num_cu == 0) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || num_cu <= 0)
-      num_cu = 256;
-  }
-  if (t.fused_packed == 2 && a.ng == 256 / LPR) {
+  FusedArgs ad = a;
+  ad.debug = t.fused_debug;
+  if (t.fused_persist) {
     // persistent + loader wave; work is drawn from per-class counters, so any grid that
     // covers the chip works (surplus workgroups find their class empty and leave)
+    static int num_cu = 0;
+    if (num_cu == 0) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess ||
+          hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || num_cu <= 0)
+        num_cu = 256;
+    }
     const size_t bufw = (size_t)a.max_rec_words + 2 * a.cap + a.rows_cap;
     const size_t lds_w = (size_t)a.cap * TW * 4 + 2 * bufw * 4 + 16;
     hipError_t e = hipMemsetAsync(a.counters, 0, 512, stream);
@@ -1358,73 +696,30 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
     if (per_cu < 1) per_cu = 1;
     const int want = t.fused_grid > 0 ? t.fused_grid : num_cu * per_cu;
     const int nwg = std::max(8, std::min((a.npanels + 7) / 8 * 8, want));
-    FusedArgs aw = a;
-    aw.debug = t.fused_debug;
     if (t.fused_u == 8)
-      hipLaunchKernelGGL((fused_packed_ws_kernel<LPR, VEC, 8>), dim3(nwg, col_tiles), dim3(320), lds_w, stream, aw);
+      hipLaunchKernelGGL((fused_packed_ws_kernel<LPR, VEC, 8>), dim3(nwg, col_tiles), dim3(320), lds_w, stream, ad);
     else
-      hipLaunchKernelGGL((fused_packed_ws_kernel<LPR, VEC, 4>), dim3(nwg, col_tiles), dim3(320), lds_w, stream, aw);
+      hipLaunchKernelGGL((fused_packed_ws_kernel<LPR, VEC, 4>), dim3(nwg, col_tiles), dim3(320), lds_w, stream, ad);
     return hipGetLastError();
   }
-  if (t.fused_packed && a.ng == 256 / LPR) {
-    const size_t lds_p = (size_t)a.cap * TW * 4 + (size_t)a.max_rec_words * 4 +
-                         (size_t)(2 * a.cap + a.rows_cap) * 4 + 16;
-    FusedArgs ap = a;
-    ap.debug = t.fused_debug;
-    if constexpr (VEC == 4) {
-      const bool fast = t.fused_fast && a.x_bytes > 0 && a.nrows_x < (1 << 24) && a.F < (1 << 22) &&
-                        (!a.Xe_mat || a.mat_bytes > 0);
-      if (fast) {
-        if (t.fused_u == 4)
-          hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 4, true>), grid, dim3(256), lds_p, stream, ap);
-        else
-          hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 8, true>), grid, dim3(256), lds_p, stream, ap);
-        return hipGetLastError();
-      }
+  const dim3 grid(a.npanels, col_tiles);
+  const size_t lds_p = (size_t)a.cap * TW * 4 + (size_t)a.max_rec_words * 4 +
+                       (size_t)(2 * a.cap + a.rows_cap) * 4 + 16;
+  if constexpr (VEC == 4) {
+    const bool fast = t.fused_fast && a.x_bytes > 0 && a.nrows_x < (1 << 24) && a.F < (1 << 22) &&
+                      (!a.Xe_mat || a.mat_bytes > 0);
+    if (fast) {
+      if (t.fused_u == 4)
+        hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 4, true>), grid, dim3(256), lds_p, stream, ad);
+      else
+        hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 8, true>), grid, dim3(256), lds_p, stream, ad);
+      return hipGetLastError();
     }
-    if (t.fused_u == 4)
-      hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 4, false>), grid, dim3(256), lds_p, stream, ap);
-    else
-      hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 8, false>), grid, dim3(256), lds_p, stream, ap);
-    return hipGetLastError();
   }
-  if (t.fused_ws) {
-    // wave-specialised persistent kernel: 4 compute waves + 1 loader wave, two list buffers.
-    // Grid = workgroups resident at once, from the LDS footprint (the binding resource here);
-    // a larger grid would run a second, mostly idle round.
-    const size_t ldw = (size_t)(a.cap + 1) + 3 * (size_t)a.cap + a.mem_cap + (a.rows_cap + 1) +
-                       2 * (size_t)a.rows_cap + (a.vslot_cap + 1) / 2 + 4;
-    const size_t lds_ws = (size_t)a.cap * TW * 4 + 2 * ldw * 4 + 16;
-    int per_cu = (int)std::min<size_t>(6, (160 * 1024) / (lds_ws + 256));  // 6 x 5 waves <= 32 waves/CU
-    if (per_cu < 1) per_cu = 1;
-    const int want = t.fused_grid > 0 ? t.fused_grid : num_cu * per_cu;
-    const int nwg = std::min(a.npanels, want);
-    if (t.fused_u == 16)
-      hipLaunchKernelGGL((fused_ws_kernel<LPR, VEC, 16>), dim3(nwg, col_tiles), dim3(320), lds_ws, stream, a);
-    else if (t.fused_u == 8)
-      hipLaunchKernelGGL((fused_ws_kernel<LPR, VEC, 8>), dim3(nwg, col_tiles), dim3(320), lds_ws, stream, a);
-    else
-      hipLaunchKernelGGL((fused_ws_kernel<LPR, VEC, 4>), dim3(nwg, col_tiles), dim3(320), lds_ws, stream, a);
-    return hipGetLastError();
-  }
-  if (t.fused_persist && a.cap <= 256 && a.mem_cap <= 1024 && a.rows_cap <= 256 && a.vslot_cap <= 512) {
-    // persistent grid: as many workgroups as the chip holds at once (an oversized grid
-    // would only queue: workgroups never wait for each other)
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_persist_kernel<LPR, VEC, 4>, 256, lds) !=
-            hipSuccess || per_cu <= 0)
-      per_cu = 4;
-    const int want = t.fused_grid > 0 ? t.fused_grid : num_cu * per_cu;
-    const int nwg = std::min(a.npanels, want);
-    hipLaunchKernelGGL((fused_persist_kernel<LPR, VEC, 4>), dim3(nwg, col_tiles), dim3(256), lds, stream, a);
-    return hipGetLastError();
-  }
-  FusedArgs ad = a;
-  ad.debug = t.fused_debug;
-  if (t.fused_u == 8)
-    hipLaunchKernelGGL((fused_panel_kernel<LPR, VEC, 8, 256>), grid, dim3(256), lds, stream, ad);
+  if (t.fused_u == 4)
+    hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 4, false>), grid, dim3(256), lds_p, stream, ad);
   else
-    hipLaunchKernelGGL((fused_panel_kernel<LPR, VEC, 4, 256>), grid, dim3(256), lds, stream, ad);
+    hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 8, false>), grid, dim3(256), lds_p, stream, ad);
   return hipGetLastError();
 }
 
@@ -1447,8 +742,6 @@ hipError_t launch_fused(const FusedArgs &a, bool vec4, hipStream_t stream) {
 #undef HG_CASE
   return hipErrorInvalidValue;
 }
-
-bool fused_use_dma() { return tuning().fused_dma != 0; }
 
 hipError_t read_stamps(unsigned long long *out, bool reset) {
   hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(hg_stamps), sizeof(hg_stamps));

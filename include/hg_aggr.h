@@ -74,8 +74,7 @@ typedef struct hg_plan_opts {
   int32_t panel_nnz;  /* index entries staged in LDS per panel (default 1024)         */
   int32_t flags;      /* HG_PLAN_* bits                                              */
   int32_t t_big;      /* fused: recompute hyperedges of at most this many members (8)  */
-  int32_t fused_tile_bytes; /* fused, register-staged kernel: LDS tile budget (16384)    */
-  int32_t fused_stage_bytes; /* fused, LDS-DMA kernel: LDS landing zone for gathered rows (32768) */
+  int32_t fused_tile_bytes; /* fused: LDS tile budget per workgroup -> slots per panel (16384) */
 } hg_plan_opts;
 
 #define HG_PLAN_HOST_ONLY 1 /* build the schedule on the host, upload nothing (tests) */
