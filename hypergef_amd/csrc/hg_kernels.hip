@@ -223,9 +223,14 @@ __global__ __launch_bounds__(256) void fixup_rows_kernel(const GatherArgs a, con
   acc.store(a.dst + drow * F + col);
 }
 
-// Diagnostic stamps (debug bit 32): lane 0 of every wave adds the cycles since
-// the previous stamp to a global counter per phase.  Never on in production.
+// Diagnostic stamps: lane 0 of every wave adds the ticks since the previous stamp to a
+// global counter per phase.  Compiled only into the diagnostic library (`make stamps`,
+// -DHG_STAMPS, then HG_FUSED_DEBUG bit 32); the production kernels carry no stamp code.
 __device__ unsigned long long hg_stamps[8];
+#ifdef HG_STAMPS
+#define HG_STAMP_INIT(cond)                                                  \
+  const bool stamp = ((a.debug & 32) != 0) && (cond) && (threadIdx.x & 63) == 0; \
+  unsigned long long t0 = stamp ? __builtin_amdgcn_s_memtime() : 0
 #define HG_STAMP(i)                                                        \
   do {                                                                     \
     if (stamp) {                                                           \
@@ -234,6 +239,10 @@ __device__ unsigned long long hg_stamps[8];
       t0 = t1;                                                             \
     }                                                                      \
   } while (0)
+#else
+#define HG_STAMP_INIT(cond) do { } while (0)
+#define HG_STAMP(i) do { } while (0)
+#endif
 
 // Packed form of the fused panel kernel.  The plan hands every panel over as ONE
 // contiguous int32 record (hg_fused.cpp, pack_records): a single coalesced copy
@@ -271,8 +280,7 @@ __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
     const int cpx = a.npanels >> 3, rem = a.npanels & 7;
     b = x * cpx + (x < rem ? x : rem) + i;
   }
-  const bool stamp = (a.debug & 32) && (threadIdx.x & 63) == 0;
-  unsigned long long t0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+  HG_STAMP_INIT(true);
   const FRec rt = a.rec_tab[b];
   HG_STAMP(0);
   const int32_t *grec = a.rec + rt.off;
@@ -477,8 +485,7 @@ __global__ __launch_bounds__(320) void fused_packed_ws_kernel(const FusedArgs a)
     int32_t *nxt = (it & 1) ? buf0 : buf1;
     const int steps = rec[0];
     if (steps < 0) break;  // same LDS word for every wave: uniform exit
-    const bool stamp = (a.debug & 32) && !loader && (threadIdx.x & 63) == 0;
-    unsigned long long t0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+    HG_STAMP_INIT(!loader);
     if (loader) {
       const int lane = tid - CT;
       const int len = start_load(nxt, lane);
