@@ -55,6 +55,8 @@ def parse():
     p.add_argument("--panel-rows", type=int, default=0)
     p.add_argument("--panel-nnz", type=int, default=0)
     p.add_argument("--no-xcd-remap", action="store_true")
+    p.add_argument("--share-gpu", action="store_true",
+                   help="rehearse the N>1 path on one GPU: all ranks use cuda:0, gloo instead of RCCL")
     return p.parse_args()
 
 
@@ -147,6 +149,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.share_gpu:  # rehearsal on a one-GPU box: every rank on cuda:0, collectives over gloo
+        local_rank = 0
     if world != max(args.gpus, 1):
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
@@ -156,7 +160,10 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     def barrier():
         if world > 1:
