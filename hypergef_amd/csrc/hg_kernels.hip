@@ -395,8 +395,8 @@ __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
   HG_STAMP(5);
 }
 
-// Chunked form of fused_packed_kernel: a workgroup walks `chunk` consecutive panels and,
-// while it works on panel p, already holds panel p+1's record (one or two dwordx4 per
+// Multi-panel form of fused_packed_kernel: a workgroup walks about `chunk` panels and,
+// while it works on one, already holds the next one's record (one or two dwordx4 per
 // thread) and scales in registers -- issued right after the barrier that opens panel p, so
 // the descriptor -> record latency (a third of a panel's residence time in the one-panel
 // kernel) is paid once per workgroup.  The prefetch is small enough not to delay the row
@@ -414,14 +414,21 @@ __global__ __launch_bounds__(256) void fused_packed_multi_kernel(const FusedArgs
   const int col = blockIdx.y * TW + lcol;
   const bool col_ok = col < a.F;
   const int64_t F = a.F;
-  const int nchunks = (a.npanels + a.chunk - 1) / a.chunk;
-  int c = blockIdx.x;
-  if (a.xcd_remap) {
-    const int x = c & 7, i = c >> 3;
-    const int cpx = nchunks >> 3, rem = nchunks & 7;
-    c = x * cpx + (x < rem ? x : rem) + i;
+  // panel sequence of this workgroup: its XCD class owns one contiguous eighth of the
+  // panels and the class's workgroups interleave over it (j, j + J, j + 2J, ...), so the
+  // panels in flight on an XCD at any moment are neighbours and share its L2
+  int p0, pstep, p1;
+  {
+    const int w = blockIdx.x, G = gridDim.x;
+    const int x = w & 7, j = w >> 3;
+    const int J = (G - x + 7) >> 3;
+    const int cpx = a.npanels >> 3, rem = a.npanels & 7;
+    const int start = x * cpx + (x < rem ? x : rem);
+    p0 = start + j;
+    pstep = J;
+    p1 = start + cpx + (x < rem ? 1 : 0);
   }
-  const int p0 = c * a.chunk, p1 = min(p0 + a.chunk, a.npanels);
+  if (p0 >= p1) return;
 
   float *tile = reinterpret_cast<float *>(smem);        // [cap * TW]
   int32_t *rec = smem + a.cap * TW;                      // [max_rec_words], 16-byte aligned
@@ -482,12 +489,12 @@ __global__ __launch_bounds__(256) void fused_packed_multi_kernel(const FusedArgs
     rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.Xe_mat ? a.Xe_mat : a.X), 0,
                                            a.Xe_mat ? a.mat_bytes : 0, 0x00020000);
   }
-  for (int p = p0; p < p1; p++) {
+  for (int p = p0; p < p1; p += pstep) {
     lds_barrier();  // record p and its scales are in LDS
-    const bool has_next = p + 1 < p1;
+    const bool has_next = p + pstep < p1;
     FRec rn = rt;
     if (has_next) {
-      rn = a.rec_tab[p + 1];
+      rn = a.rec_tab[p + pstep];
       fetch(rn, P);
     }
     const int steps = rec[0], nrows = rec[1];
@@ -873,7 +880,8 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
   if (t.fused_chunk > 1 && a.max_rec_words <= 2048 && a.cap <= 256 && a.rows_cap <= 256) {
     const size_t lds_c = (size_t)a.cap * TW * 4 + (size_t)a.max_rec_words * 4 + (size_t)(2 * a.cap + a.rows_cap) * 4 + 16;
     ad.chunk = t.fused_chunk;
-    const dim3 gridc((a.npanels + ad.chunk - 1) / ad.chunk, col_tiles);
+    const int nwgc = std::max(8, ((a.npanels + ad.chunk - 1) / ad.chunk + 7) / 8 * 8);
+    const dim3 gridc(nwgc, col_tiles);
     if constexpr (VEC == 4) {
       const bool fast = t.fused_fast && a.x_bytes > 0 && a.nrows_x < (1 << 24) && a.F < (1 << 22) &&
                         (!a.Xe_mat || a.mat_bytes > 0);
