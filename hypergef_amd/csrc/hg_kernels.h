@@ -42,7 +42,6 @@ struct FusedArgs {
   int32_t x_bytes;        // byte size of X if it fits a buffer descriptor (< 2 GiB), else 0
   int32_t mat_bytes;      // same for the materialised table
   int32_t nrows_x;        // rows of X
-  int32_t chunk = 1;      // consecutive panels per workgroup (chunked kernel)
   int32_t debug = 0;      // ablation / stamp bits (experiments only)
 };
 

@@ -395,172 +395,6 @@ __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
   HG_STAMP(5);
 }
 
-// Multi-panel form of fused_packed_kernel: a workgroup walks about `chunk` panels and,
-// while it works on one, already holds the next one's record (one or two dwordx4 per
-// thread) and scales in registers -- issued right after the barrier that opens panel p, so
-// the descriptor -> record latency (a third of a panel's residence time in the one-panel
-// kernel) is paid once per workgroup.  The prefetch is small enough not to delay the row
-// gathers queued behind it.  All barriers are LDS-only, so Y stores stay in flight.
-template <int LPR, int VEC, int U, bool FAST>
-__global__ __launch_bounds__(256) void fused_packed_multi_kernel(const FusedArgs a) {
-  constexpr int BS = 256;
-  constexpr int NG = BS / LPR;
-  constexpr int TW = LPR * VEC;
-  using V = Vec<VEC>;
-  extern __shared__ int32_t smem[];
-  const int tid = threadIdx.x;
-  const int gl = tid & (LPR - 1);
-  const int lcol = gl * VEC;
-  const int col = blockIdx.y * TW + lcol;
-  const bool col_ok = col < a.F;
-  const int64_t F = a.F;
-  // panel sequence of this workgroup: its XCD class owns one contiguous eighth of the
-  // panels and the class's workgroups interleave over it (j, j + J, j + 2J, ...), so the
-  // panels in flight on an XCD at any moment are neighbours and share its L2
-  int p0, pstep, p1;
-  {
-    const int w = blockIdx.x, G = gridDim.x;
-    const int x = w & 7, j = w >> 3;
-    const int J = (G - x + 7) >> 3;
-    const int cpx = a.npanels >> 3, rem = a.npanels & 7;
-    const int start = x * cpx + (x < rem ? x : rem);
-    p0 = start + j;
-    pstep = J;
-    p1 = start + cpx + (x < rem ? 1 : 0);
-  }
-  if (p0 >= p1) return;
-
-  float *tile = reinterpret_cast<float *>(smem);        // [cap * TW]
-  int32_t *rec = smem + a.cap * TW;                      // [max_rec_words], 16-byte aligned
-  float *sA = reinterpret_cast<float *>(rec + a.max_rec_words);  // [cap]
-  float *sB = sA + a.cap;                                // [cap]
-  float *sdeg = sB + a.cap;                              // [rows_cap]
-  const bool weighted = a.degE || a.W || a.degV;
-
-  // one panel's record + scales, strided over the threads (len <= 2048 words, cap, rows <= 256)
-  struct Pre {
-    hg_i4 r0, r1;
-    float sa, sb, sd;
-  };
-  auto fetch = [&](const FRec &rt, Pre &P) {
-    const hg_i4 *g4 = reinterpret_cast<const hg_i4 *>(a.rec + rt.off);
-    const int n4 = rt.len >> 2;
-    const hg_i4 z = {0, 0, 0, 0};
-    P.r0 = tid < n4 ? g4[tid] : z;
-    P.r1 = tid + BS < n4 ? g4[tid + BS] : z;
-    P.sa = P.sb = P.sd = 1.f;
-    if (weighted) {
-      const int32_t *grec = a.rec + rt.off;
-      if ((a.degE || a.W) && tid < rt.nslots) {
-        if (a.bsA) {
-          P.sa = a.bsA[rt.slot_base + tid];
-          P.sb = a.bsB[rt.slot_base + tid];
-        } else {
-          const int e = grec[rt.off_eid + tid];
-          if (a.degE && e >= 0) P.sa = a.degE[e];
-          if (a.W && e >= 0) P.sb = a.W[e];
-        }
-      }
-      if (a.degV && tid < rt.nrows) P.sd = a.bsD ? a.bsD[rt.row_base + tid] : a.degV[grec[rt.off_prow + tid]];
-    }
-  };
-  auto commit = [&](const FRec &rt, const Pre &P) {
-    const int n4 = rt.len >> 2;
-    if (tid < n4) reinterpret_cast<hg_i4 *>(rec)[tid] = P.r0;
-    if (tid + BS < n4) reinterpret_cast<hg_i4 *>(rec)[tid + BS] = P.r1;
-    if (weighted) {
-      if (tid < rt.nslots) {
-        sA[tid] = P.sa;
-        sB[tid] = P.sb;
-      }
-      if (tid < rt.nrows) sdeg[tid] = P.sd;
-    }
-  };
-
-  FRec rt = a.rec_tab[p0];
-  Pre P;
-  fetch(rt, P);
-  commit(rt, P);
-  const int g = tid / LPR;
-  [[maybe_unused]] const unsigned row_bytes = (unsigned)a.F * 4u, col_bytes = (unsigned)col * 4u;
-  [[maybe_unused]] __amdgpu_buffer_rsrc_t rx, rm;
-  if constexpr (FAST) {
-    rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.X), 0, a.x_bytes, 0x00020000);
-    rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.Xe_mat ? a.Xe_mat : a.X), 0,
-                                           a.Xe_mat ? a.mat_bytes : 0, 0x00020000);
-  }
-  for (int p = p0; p < p1; p += pstep) {
-    lds_barrier();  // record p and its scales are in LDS
-    const bool has_next = p + pstep < p1;
-    FRec rn = rt;
-    if (has_next) {
-      rn = a.rec_tab[p + pstep];
-      fetch(rn, P);
-    }
-    const int steps = rec[0], nrows = rec[1];
-    const int32_t *gbase = rec + rec[4];
-    const int32_t *stream = rec + rec[5];
-    const int32_t *pend = rec + rec[6];
-    const int32_t *prow = rec + rec[7];
-    const uint16_t *pvs = reinterpret_cast<const uint16_t *>(rec + rec[9]);
-    {  // ---- hop 1
-      int slot = gbase[g];
-      V acc = V::zero();
-      for (int s0 = 0; s0 < steps; s0 += U) {
-        int ent[U];
-#pragma unroll
-        for (int j = 0; j < U; j++) ent[j] = (s0 + j < steps) ? stream[(s0 + j) * NG + g] : -1;
-        V v[U];
-#pragma unroll
-        for (int j = 0; j < U; j++) {
-          const bool on = col_ok && ent[j] != -1;
-          if constexpr (FAST) {
-            const unsigned off = __umul24((unsigned)ent[j] & 0x3fffffffu, row_bytes) + col_bytes;
-            const bool mat = a.Xe_mat && (ent[j] & 0x40000000);
-            hg_u4 q = {0u, 0u, 0u, 0u};
-            if (on && !mat) q = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
-            if (a.Xe_mat) {
-              if (on && mat) q = __builtin_amdgcn_raw_buffer_load_b128(rm, off, 0, 0);
-            }
-            v[j].v = __builtin_bit_cast(float4, q);
-          } else {
-            const int64_t idx = ent[j] & 0x3fffffff;
-            const float *base = (a.Xe_mat && (ent[j] & 0x40000000)) ? a.Xe_mat : a.X;
-            v[j] = on ? V::load(base + idx * F + col) : V::zero();
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < U; j++) {
-          acc.add(v[j]);
-          if (ent[j] < -1) {
-            if (a.degE) acc.mul(sA[slot]);
-            if (a.W) acc.mul(sB[slot]);
-            acc.store(tile + slot * TW + lcol);
-            slot++;
-            acc = V::zero();
-          }
-        }
-      }
-    }
-    lds_barrier();
-    {  // ---- hop 2
-      const int rpg = (nrows + NG - 1) / NG;
-      const int r0 = min(g * rpg, nrows), r1 = min(r0 + rpg, nrows);
-      for (int r = r0; r < r1; r++) {
-        V acc = V::zero();
-        const int pb = r ? pend[r - 1] : 0, pe = pend[r];
-        for (int q = pb; q < pe; q++) acc.add(V::load(tile + (int)pvs[q] * TW + lcol));
-        if (a.degV && pe > pb) acc.mul(sdeg[r]);
-        if (col_ok) acc.store(a.Y + (int64_t)prow[r] * F + col);
-      }
-    }
-    if (!has_next) break;
-    lds_barrier();  // every wave is done with record p and the tile
-    rt = rn;
-    commit(rt, P);
-  }
-}
-
 // one wave copies n dwords global -> LDS with global_load_lds (64 dwords per instruction;
 // the LDS destination is wave-uniform base + lane * 4 B, the source address is per lane).
 // Sub-dword sizes are not used: a 2-byte global_load_lds does not land 2-byte granules.
@@ -775,7 +609,6 @@ struct Tuning {
   int fused_fast = 1;    // HG_FUSED_FAST=0      : global loads instead of buffer loads
   int fused_coltile = 0; // HG_FUSED_COLTILE=1   : 128-byte column tiles for wide rows
   int fused_grid = 0;    // HG_FUSED_GRID=n      : workgroups of the persistent kernel
-  int fused_chunk = 1;   // HG_FUSED_CHUNK=k     : consecutive panels per workgroup (record prefetch)
   int fused_debug = 0;   // HG_FUSED_DEBUG=bits  : ablation / stamp switches (timing only)
 };
 static const Tuning &tuning() {
@@ -788,7 +621,6 @@ static const Tuning &tuning() {
     if (const char *e = getenv("HG_FUSED_FAST")) x.fused_fast = atoi(e) != 0;
     if (const char *e = getenv("HG_FUSED_COLTILE")) x.fused_coltile = atoi(e) != 0;
     if (const char *e = getenv("HG_FUSED_GRID")) x.fused_grid = atoi(e);
-    if (const char *e = getenv("HG_FUSED_CHUNK")) x.fused_chunk = std::max(1, atoi(e));
     if (const char *e = getenv("HG_FUSED_DEBUG")) x.fused_debug = atoi(e);
     return x;
   }();
@@ -875,22 +707,6 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
       hipLaunchKernelGGL((fused_packed_ws_kernel<LPR, VEC, 8>), dim3(nwg, col_tiles), dim3(320), lds_w, stream, ad);
     else
       hipLaunchKernelGGL((fused_packed_ws_kernel<LPR, VEC, 4>), dim3(nwg, col_tiles), dim3(320), lds_w, stream, ad);
-    return hipGetLastError();
-  }
-  if (t.fused_chunk > 1 && a.max_rec_words <= 2048 && a.cap <= 256 && a.rows_cap <= 256) {
-    const size_t lds_c = (size_t)a.cap * TW * 4 + (size_t)a.max_rec_words * 4 + (size_t)(2 * a.cap + a.rows_cap) * 4 + 16;
-    ad.chunk = t.fused_chunk;
-    const int nwgc = std::max(8, ((a.npanels + ad.chunk - 1) / ad.chunk + 7) / 8 * 8);
-    const dim3 gridc(nwgc, col_tiles);
-    if constexpr (VEC == 4) {
-      const bool fast = t.fused_fast && a.x_bytes > 0 && a.nrows_x < (1 << 24) && a.F < (1 << 22) &&
-                        (!a.Xe_mat || a.mat_bytes > 0);
-      if (fast) {
-        hipLaunchKernelGGL((fused_packed_multi_kernel<LPR, VEC, 8, true>), gridc, dim3(256), lds_c, stream, ad);
-        return hipGetLastError();
-      }
-    }
-    hipLaunchKernelGGL((fused_packed_multi_kernel<LPR, VEC, 8, false>), gridc, dim3(256), lds_c, stream, ad);
     return hipGetLastError();
   }
   const dim3 grid(a.npanels, col_tiles);
