@@ -604,7 +604,8 @@ static inline int next_pow2(int x) {
 struct Tuning {
   int unroll = 4;        // HG_UNROLL = 4|8      : row loads in flight per lane, pull kernel
   int pipe = 0;          // HG_PIPE = 0|1        : two batches in flight, pull kernel
-  int fused_u = 8;       // HG_FUSED_U = 4|8     : row loads in flight per lane, fused kernel
+  int fused_u = 8;       // HG_FUSED_U = 4|8|16  : row loads in flight per lane, fused kernel
+  int fused_small16 = 1; // HG_FUSED_SMALL16=0   : no U = 16 for grids of at most 512 panels
   int fused_persist = 0; // HG_FUSED_PERSIST=1   : persistent kernel with a loader wave
   int fused_fast = 1;    // HG_FUSED_FAST=0      : global loads instead of buffer loads
   int fused_coltile = 0; // HG_FUSED_COLTILE=1   : 128-byte column tiles for wide rows
@@ -616,7 +617,8 @@ static const Tuning &tuning() {
     Tuning x;
     if (const char *e = getenv("HG_UNROLL")) x.unroll = atoi(e) == 8 ? 8 : 4;
     if (const char *e = getenv("HG_PIPE")) x.pipe = atoi(e) != 0;
-    if (const char *e = getenv("HG_FUSED_U")) x.fused_u = atoi(e) == 4 ? 4 : 8;
+    if (const char *e = getenv("HG_FUSED_U")) x.fused_u = atoi(e) == 4 ? 4 : (atoi(e) == 16 ? 16 : 8);
+    if (const char *e = getenv("HG_FUSED_SMALL16")) x.fused_small16 = atoi(e) != 0;
     if (const char *e = getenv("HG_FUSED_PERSIST")) x.fused_persist = atoi(e) != 0;
     if (const char *e = getenv("HG_FUSED_FAST")) x.fused_fast = atoi(e) != 0;
     if (const char *e = getenv("HG_FUSED_COLTILE")) x.fused_coltile = atoi(e) != 0;
@@ -716,7 +718,11 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
     const bool fast = t.fused_fast && a.x_bytes > 0 && a.nrows_x < (1 << 24) && a.F < (1 << 22) &&
                       (!a.Xe_mat || a.mat_bytes > 0);
     if (fast) {
-      if (t.fused_u == 4)
+      // A grid that does not even fill the chip once is latency-bound, not occupancy-bound:
+      // put every row gather of a group in flight at once (U = 16) instead of two batches.
+      if (t.fused_u == 16 || (t.fused_small16 && a.npanels <= 512))
+        hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 16, true>), grid, dim3(256), lds_p, stream, ad);
+      else if (t.fused_u == 4)
         hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 4, true>), grid, dim3(256), lds_p, stream, ad);
       else
         hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 8, true>), grid, dim3(256), lds_p, stream, ad);
