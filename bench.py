@@ -187,6 +187,9 @@ def main():
     t0 = time.perf_counter()
     plan = planmod.Plan.from_tensors(inc.N, ptr, ind, opts)
     plan_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    fused_shape = plan.prepare(F) if plan.auto_variant(F) == "fused" or args.variant == "fused" else None
+    prepare_s = time.perf_counter() - t0
     degE = degV = W = None
     n_w = 0
     if args.weighted:
@@ -242,7 +245,7 @@ def main():
                      "algorithmic_bytes_per_launch": balg / launches,
                      "avg_launch_us": kern_avg_s * 1e6, "launches_per_step": launches},
         "hbm_gbs_algorithmic": balg * world * args.steps / wall / 1e9,
-        "plan_build_s": plan_s,
+        "plan_build_s": plan_s, "fused_schedule_build_s": prepare_s, "fused_schedule": fused_shape,
         "plan": {k: plan.info[k] for k in ("panels", "tasks", "fixups", "max_len", "short_max",
                                             "panel_rows", "panel_nnz")},
     }
