@@ -139,3 +139,56 @@ def write_mtx(path, inc):
         f.write("%d %d %d\n" % (inc.N, inc.M, inc.nnz))
         for vi, ei in zip(v[order], e[order]):
             f.write("%d %d 1.0\n" % (vi + 1, ei + 1))
+
+
+# Nominal AllSet / HyperGCN dataset statistics (vertices, hyperedges, incidences, largest
+# hyperedge) for the 13 datasets of the reference's result table (experiment/example_data/
+# result.xlsx, sheet "fig7,fig9").  The datasets themselves are downloaded by the reference
+# (HyperGsys/data/prepare.sh) and are not available offline; these are the published shapes,
+# quoted as nominal, used only to size synthetic stand-ins.
+ALLSET_SHAPES = {
+    "cora": (2708, 1579, 4859, 5),
+    "citeseer": (3312, 1079, 3453, 26),
+    "pubmed": (19717, 7963, 34629, 171),
+    "coauthor_cora": (2708, 1072, 4585, 43),
+    "coauthor_dblp": (41302, 22363, 99561, 202),
+    "NTU2012": (2012, 2012, 10060, 5),
+    "ModelNet40": (12311, 12311, 61555, 5),
+    "zoo": (101, 43, 1717, 93),
+    "Mushroom": (8124, 298, 40620, 1808),
+    "20newsW100": (16242, 100, 65451, 2241),
+    "house-committees": (1290, 341, 11843, 82),
+    "walmart-trips": (88860, 69906, 460630, 25),
+    "yelp": (50758, 679302, 2931130, 2838),
+}
+
+
+def allset_shape(name, seed=0):
+    """Synthetic stand-in with the named dataset's nominal size: hyperedge sizes from a
+    truncated power law fitted to (mean, max), members uniform without replacement."""
+    N, M, nnz, smax = ALLSET_SHAPES[name]
+    rng = np.random.default_rng(seed + sum(map(ord, name)))
+    mean = nnz / M
+    smin = 2 if mean >= 2.5 else 1
+    smax = min(smax, N)
+    if smax <= 6 or mean >= smax * 0.9:  # k-uniform (kNN-built) hypergraphs
+        sizes = np.full(M, int(round(mean)), np.int64)
+    else:
+        lo, hi = 0.3, 6.0  # tail exponent: bisect until the mean matches
+        u = rng.random(M)
+        for _ in range(40):
+            t = 0.5 * (lo + hi)
+            sizes = np.clip(np.floor(smin * u ** (-1.0 / t)), smin, smax)
+            if sizes.mean() > mean:
+                lo = t
+            else:
+                hi = t
+        sizes = sizes.astype(np.int64)
+    total = int(sizes.sum())
+    eid = np.repeat(np.arange(M, dtype=np.int64), sizes)
+    mem = rng.integers(0, N, size=total).astype(np.int64)
+    key = np.unique(eid * N + mem)  # de-duplicate inside each hyperedge (sizes shrink slightly)
+    eid, mem = key // N, key % N
+    csrptr = np.zeros(M + 1, np.int64)
+    np.add.at(csrptr, eid + 1, 1)
+    return Incidence(N, M, np.cumsum(csrptr).astype(np.int32), mem.astype(np.int32), name=name + "-shape")
