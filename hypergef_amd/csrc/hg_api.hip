@@ -138,8 +138,8 @@ int get_fused(const hg_plan *cp, int32_t F, bool vec4, const hg::FusedSched **ou
     hg::Opts o = p->opts;
     // A small hypergraph is launch-bound: when every hyperedge fits a panel's stream anyway,
     // recompute them all and save the materialisation launch (one citeseer-shape hypergraph:
-    // 15.8 -> 8.2 us).  Large inputs keep t_big: there the extra gathers cost more than a launch.
-    if (p->nnz <= (1 << 18) && p->sched[0].max_len <= o.short_max && p->sched[0].max_len * 4 <= mem_cap)
+    // 15.8 -> 8.2 us; coauthor_cora-shape 12.6 -> see profiles/r01_shape_sweep.md).  Large inputs keep t_big: there the extra gathers cost more than a launch.
+    if (p->nnz <= (1 << 18) && p->sched[0].max_len * 4 <= mem_cap)
       o.t_big = std::max(o.t_big, p->sched[0].max_len);
     try {
       hg::build_fused(p->N, p->M, p->ptr_t.data(), p->ind_t.data(), p->ptr_v.data(), p->ind_v.data(),
