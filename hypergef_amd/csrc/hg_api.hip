@@ -136,14 +136,18 @@ int get_fused(const hg_plan *cp, int32_t F, bool vec4, const hg::FusedSched **ou
   if (it == p->fused.end()) {
     hg::FusedSched f;
     hg::Opts o = p->opts;
-    // A small hypergraph is launch-bound: when every hyperedge fits a panel's stream anyway,
-    // recompute them all and save the materialisation launch (one citeseer-shape hypergraph:
-    // 15.8 -> 8.2 us; coauthor_cora-shape 12.6 -> see profiles/r01_shape_sweep.md).  Large inputs keep t_big: there the extra gathers cost more than a launch.
-    if (p->nnz <= (1 << 18) && p->sched[0].max_len * 4 <= mem_cap)
+    // A small hypergraph is launch-bound: recompute every hyperedge inside the panels (long ones
+    // cut into sub-slots of 8 members that meet again in hop 2) and save the materialisation
+    // launch: one citeseer-shape hypergraph 15.8 -> 8 us, coauthor_cora-shape 12.6 -> 9.6 us.
+    // Large inputs keep t_big: there the repeated gathers cost more than a launch.
+    int32_t split = 0;
+    if (p->nnz <= (1 << 18) && p->sched[0].max_len <= mem_cap / 2) {
       o.t_big = std::max(o.t_big, p->sched[0].max_len);
+      split = 8;
+    }
     try {
       hg::build_fused(p->N, p->M, p->ptr_t.data(), p->ind_t.data(), p->ptr_v.data(), p->ind_v.data(),
-                      o, cap, mem_cap, ng, f);
+                      o, cap, mem_cap, ng, split, f);
     } catch (const std::bad_alloc &) {
       hg::set_error("fused schedule: host allocation failed");
       return HG_ERR_NOMEM;

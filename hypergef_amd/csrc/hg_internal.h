@@ -123,7 +123,7 @@ void transpose_csr(int32_t nrows, int32_t ncols, const int32_t *ptr,
 void build_sched(int32_t nrows, const int32_t *ptr, const Opts &o, Sched &s);
 void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_t,
                  const int32_t *ptr_v, const int32_t *ind_v, const Opts &o, int32_t cap,
-                 int32_t mem_cap, int32_t ng, FusedSched &f);
+                 int32_t mem_cap, int32_t ng, int32_t split, FusedSched &f);
 
 }  // namespace hg
 
