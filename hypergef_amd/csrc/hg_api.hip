@@ -135,19 +135,23 @@ int get_fused(const hg_plan *cp, int32_t F, bool vec4, const hg::FusedSched **ou
   auto it = p->fused.find(key);
   if (it == p->fused.end()) {
     hg::FusedSched f;
-    hg::Opts o = p->opts;
-    // A small hypergraph is launch-bound: recompute every hyperedge inside the panels (long ones
-    // cut into sub-slots of 8 members that meet again in hop 2) and save the materialisation
-    // launch: one citeseer-shape hypergraph 15.8 -> 8 us, coauthor_cora-shape 12.6 -> 9.6 us.
-    // Large inputs keep t_big: there the repeated gathers cost more than a launch.
-    int32_t split = 0;
-    if (p->nnz <= (1 << 18) && p->sched[0].max_len <= mem_cap / 2) {
-      o.t_big = std::max(o.t_big, p->sched[0].max_len);
-      split = 8;
-    }
     try {
       hg::build_fused(p->N, p->M, p->ptr_t.data(), p->ind_t.data(), p->ptr_v.data(), p->ind_v.data(),
-                      o, cap, mem_cap, ng, split, f);
+                      p->opts, cap, mem_cap, ng, f);
+      // A small hypergraph is launch-bound.  If the default schedule needs a materialisation
+      // launch only because of a few longish hyperedges, try recomputing them too and keep
+      // that schedule when the launch saved (~5 us) outweighs its longer streams (~0.08 us
+      // per step of the longest panel): one citeseer-shape hypergraph 15.8 -> 8.2 us,
+      // coauthor_cora-shape 12.6 -> 9.6 us at F = 32; pubmed-shape keeps materialising.
+      if (p->nnz <= (1 << 18) && f.n_mat > 0 && f.n_hub == 0 && p->sched[0].max_len * 4 <= mem_cap) {
+        hg::Opts o = p->opts;
+        o.t_big = std::max(o.t_big, p->sched[0].max_len);
+        hg::FusedSched alt;
+        hg::build_fused(p->N, p->M, p->ptr_t.data(), p->ind_t.data(), p->ptr_v.data(), p->ind_v.data(), o, cap,
+                        mem_cap, ng, alt);
+        const double cost_default = 10.0 + 0.08 * f.max_steps, cost_alt = 5.0 + 0.08 * alt.max_steps;
+        if (alt.n_mat == 0 && alt.n_hub == 0 && cost_alt < cost_default) f = std::move(alt);
+      }
     } catch (const std::bad_alloc &) {
       hg::set_error("fused schedule: host allocation failed");
       return HG_ERR_NOMEM;

@@ -16,39 +16,25 @@ void pack_records(FusedSched &f, int32_t ng);
 
 void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_t,
                  const int32_t *ptr_v, const int32_t *ind_v, const Opts &o, int32_t cap,
-                 int32_t mem_cap, int32_t ng, int32_t split, FusedSched &f) {
+                 int32_t mem_cap, int32_t ng, FusedSched &f) {
   f = FusedSched();
   f.cap = cap;
   f.rows_cap = cap;
   f.mem_cap = mem_cap;
   f.vslot_cap = cap * 2;
   f.t_big = std::max(1, std::min(o.t_big, f.mem_cap));
+  // a single row must always fit into an empty panel
   f.vdeg_max = std::max(1, std::min(std::min(cap, f.vslot_cap), f.mem_cap / f.t_big));
-  // `split` > 0 (small, launch-bound inputs): a recomputed hyperedge of more than `split`
-  // members becomes ceil(len/split) sub-slots whose partial sums meet again in hop 2, so a
-  // long hyperedge does not serialise one lane group (and needs no materialisation launch).
-  auto nsub = [&](int32_t e) -> int32_t {
-    const int32_t len = ptr_t[e + 1] - ptr_t[e];
-    return (split > 0 && len > split) ? (len + split - 1) / split : 1;
-  };
 
   std::vector<uint8_t> is_mat((size_t)M, 0), is_hub((size_t)N, 0);
   for (int32_t e = 0; e < M; e++)
     if (ptr_t[e + 1] - ptr_t[e] > f.t_big) is_mat[e] = 1;
-  // a single row must always fit into an empty panel: otherwise the vertex is a hub
-  for (int32_t v = 0; v < N; v++) {
-    int64_t slots = 0, mem = 0;
-    for (int32_t p = ptr_v[v]; p < ptr_v[v + 1]; p++) {
-      const int32_t e = ind_v[p];
-      slots += is_mat[e] ? 1 : nsub(e);
-      mem += is_mat[e] ? 1 : (ptr_t[e + 1] - ptr_t[e]);
-    }
-    if (ptr_v[v + 1] - ptr_v[v] > f.vdeg_max || slots > std::min(cap, f.vslot_cap) || mem > f.mem_cap) {
+  for (int32_t v = 0; v < N; v++)
+    if (ptr_v[v + 1] - ptr_v[v] > f.vdeg_max) {
       is_hub[v] = 1;
       f.n_hub++;
       for (int32_t p = ptr_v[v]; p < ptr_v[v + 1]; p++) is_mat[ind_v[p]] = 1;
     }
-  }
 
   // compact CSR of the materialised hyperedges
   std::vector<int32_t> mat_id((size_t)M, -1);
@@ -123,7 +109,7 @@ void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_
   }
 
   // fused panels over that order
-  std::vector<int32_t> stamp((size_t)M, -1), slot_of((size_t)M, 0), slot_cnt((size_t)M, 1);
+  std::vector<int32_t> stamp((size_t)M, -1), slot_of((size_t)M, 0);
   FPanel cur{};
   auto open_panel = [&]() {
     cur = FPanel{};
@@ -147,16 +133,15 @@ void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_
   open_panel();
   for (const int32_t v : order) {
     int32_t pid = (int32_t)f.panels.size();
-    int32_t new_slots = 0, new_mem = 0, deg = 0;  // deg: (vertex, slot) incidences this row adds
+    int32_t new_slots = 0, new_mem = 0;
     for (int32_t p = ptr_v[v]; p < ptr_v[v + 1]; p++) {
       const int32_t e = ind_v[p];
-      const int32_t ns = is_mat[e] ? 1 : nsub(e);
-      deg += ns;
       if (stamp[e] != pid) {  // a duplicate incidence is counted twice here; harmless
-        new_slots += ns;
+        new_slots++;
         new_mem += is_mat[e] ? 1 : (ptr_t[e + 1] - ptr_t[e]);
       }
     }
+    const int32_t deg = ptr_v[v + 1] - ptr_v[v];
     const int32_t rows = (int32_t)f.prow.size() - cur.r0;
     const int32_t cur_mem = (int32_t)f.pmem.size() - cur.pm0;
     const int32_t cur_vs = (int32_t)f.pvs.size() - cur.v0;
@@ -170,26 +155,17 @@ void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_
       const int32_t e = ind_v[p];
       if (stamp[e] != pid) {
         stamp[e] = pid;
-        slot_of[e] = cur.nslots;
+        slot_of[e] = cur.nslots++;
         if (is_mat[e]) {
-          slot_cnt[e] = 1;
-          cur.nslots++;
           f.pmem.push_back((int32_t)(0x80000000u | (uint32_t)mat_id[e]));
           f.slot_eid.push_back(-1);
-          f.soff.push_back((int32_t)f.pmem.size() - cur.pm0);
         } else {
-          const int32_t ns = nsub(e), len = ptr_t[e + 1] - ptr_t[e];
-          slot_cnt[e] = ns;
-          for (int32_t k = 0; k < ns; k++) {  // near-equal member chunks, in member order
-            const int32_t b0 = (int32_t)((int64_t)len * k / ns), b1 = (int32_t)((int64_t)len * (k + 1) / ns);
-            f.pmem.insert(f.pmem.end(), ind_t + ptr_t[e] + b0, ind_t + ptr_t[e] + b1);
-            f.slot_eid.push_back(e);
-            f.soff.push_back((int32_t)f.pmem.size() - cur.pm0);
-            cur.nslots++;
-          }
+          f.pmem.insert(f.pmem.end(), ind_t + ptr_t[e], ind_t + ptr_t[e + 1]);
+          f.slot_eid.push_back(e);
         }
+        f.soff.push_back((int32_t)f.pmem.size() - cur.pm0);
       }
-      for (int32_t k = 0; k < slot_cnt[e]; k++) f.pvs.push_back((uint16_t)(slot_of[e] + k));
+      f.pvs.push_back((uint16_t)slot_of[e]);
     }
     f.prow.push_back(v);
     f.pend.push_back((int32_t)f.pvs.size() - cur.v0);
@@ -218,6 +194,7 @@ void pack_records(FusedSched &f, int32_t ng) {
   f.rec_tab.clear();
   f.eid_all.clear();
   f.max_rec_words = 0;
+  f.max_steps = 0;
   f.stream_entries = 0;
   std::vector<int32_t> order, load, gslots, newid, stream;
   for (const FPanel &pn : f.panels) {
@@ -279,6 +256,7 @@ void pack_records(FusedSched &f, int32_t ng) {
     f.eid_all.insert(f.eid_all.end(), eid.begin(), eid.end());
     f.rec_tab.push_back(rt);
     f.max_rec_words = std::max(f.max_rec_words, words);
+    f.max_steps = std::max(f.max_steps, steps);
     f.stream_entries += (int64_t)steps * ng;
     const size_t base = f.rec.size();
     f.rec.resize(base + (size_t)words, 0);

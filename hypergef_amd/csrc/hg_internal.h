@@ -88,6 +88,7 @@ struct FusedSched {
   std::vector<int32_t> rec;   // all records, back to back
   std::vector<FRec> rec_tab;  // per panel: offset and length in words
   int32_t max_rec_words = 0;
+  int32_t max_steps = 0;       // longest hop-1 stream of any panel
   int64_t stream_entries = 0;  // steps * ng summed over panels (incl. idle steps)
   int32_t *d_rec = nullptr;
   FRec *d_rec_tab = nullptr;
@@ -123,7 +124,7 @@ void transpose_csr(int32_t nrows, int32_t ncols, const int32_t *ptr,
 void build_sched(int32_t nrows, const int32_t *ptr, const Opts &o, Sched &s);
 void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_t,
                  const int32_t *ptr_v, const int32_t *ind_v, const Opts &o, int32_t cap,
-                 int32_t mem_cap, int32_t ng, int32_t split, FusedSched &f);
+                 int32_t mem_cap, int32_t ng, FusedSched &f);
 
 }  // namespace hg
 
