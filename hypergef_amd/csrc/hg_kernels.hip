@@ -268,7 +268,10 @@ typedef int hg_i4 __attribute__((ext_vector_type(4)));
 // column bytes) instead of 64-bit pointer arithmetic; needs N < 2^24, F*4 < 2^24 and
 // tables below 2 GiB (the launcher checks; otherwise FAST = false runs the same loop
 // on global loads).
-template <int LPR, int VEC, int U, bool FAST>
+// MAT / SCALED say whether materialised slots / degE-W scaling can occur at all (the launcher
+// knows); false compiles that path out of the unrolled loop, which is issue-bound.  DBG keeps
+// the ablation switches (a.debug) in the code; production instances have none.
+template <int LPR, int VEC, int U, bool FAST, bool MAT, bool SCALED, bool DBG>
 __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
   constexpr int BS = 256;
   constexpr int NG = BS / LPR;
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
   HG_STAMP(1);
   __syncthreads();
   HG_STAMP(2);
-  if (a.debug & 16) return;  // ablation (experiments): record copy only
+  if (DBG && (a.debug & 16)) return;  // ablation (experiments): record copy only
   const int steps = rec[0], nrows = rec[1];
   const int32_t *gbase = rec + rec[4];
   const int32_t *stream = rec + rec[5];
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
   const uint16_t *pvs = reinterpret_cast<const uint16_t *>(rec + rec[9]);
 
   const int g = tid / LPR;
-  if (!(a.debug & 4)) {  // ---- hop 1
+  if (!(DBG && (a.debug & 4))) {  // ---- hop 1
     int slot = gbase[g];
     V acc = V::zero();
     [[maybe_unused]] const unsigned row_bytes = (unsigned)a.F * 4u, col_bytes = (unsigned)col * 4u;
@@ -346,19 +349,19 @@ __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
       V v[U];
 #pragma unroll
       for (int j = 0; j < U; j++) {
-        const bool on = col_ok && ent[j] != -1 && !(a.debug & 1);
+        const bool on = col_ok && ent[j] != -1 && !(DBG && (a.debug & 1));
         if constexpr (FAST) {
           const unsigned off = __umul24((unsigned)ent[j] & 0x3fffffffu, row_bytes) + col_bytes;
-          const bool mat = a.Xe_mat && (ent[j] & 0x40000000);
+          const bool mat = MAT && (ent[j] & 0x40000000);
           hg_u4 q = {0u, 0u, 0u, 0u};
           if (on && !mat) q = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
-          if (a.Xe_mat) {  // wave-uniform: only graphs with materialised hyperedges pay for it
+          if constexpr (MAT) {
             if (on && mat) q = __builtin_amdgcn_raw_buffer_load_b128(rm, off, 0, 0);
           }
           v[j].v = __builtin_bit_cast(float4, q);
         } else {
           const int64_t idx = ent[j] & 0x3fffffff;
-          const float *base = (a.Xe_mat && (ent[j] & 0x40000000)) ? a.Xe_mat : a.X;
+          const float *base = (MAT && a.Xe_mat && (ent[j] & 0x40000000)) ? a.Xe_mat : a.X;
           v[j] = on ? V::load(base + idx * F + col) : V::zero();
         }
       }
@@ -366,8 +369,10 @@ __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
       for (int j = 0; j < U; j++) {
         acc.add(v[j]);        // an idle step contributed zeros
         if (ent[j] < -1) {    // bit 31 set and not the idle word: last member of this slot
-          if (a.degE) acc.mul(sA[slot]);
-          if (a.W) acc.mul(sB[slot]);
+          if constexpr (SCALED) {
+            if (a.degE) acc.mul(sA[slot]);
+            if (a.W) acc.mul(sB[slot]);
+          }
           acc.store(tile + slot * TW + lcol);
           slot++;
           acc = V::zero();
@@ -378,7 +383,7 @@ __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
   HG_STAMP(3);
   __syncthreads();
   HG_STAMP(4);
-  if (!(a.debug & 8)) {  // ---- hop 2
+  if (!(DBG && (a.debug & 8))) {  // ---- hop 2
     const int rpg = (nrows + NG - 1) / NG;
     const int r0 = min(g * rpg, nrows), r1 = min(r0 + rpg, nrows);
     for (int r = r0; r < r1; r++) {
@@ -386,8 +391,8 @@ __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
       const int pb = r ? pend[r - 1] : 0, pe = pend[r];
       for (int p = pb; p < pe; p++) acc.add(V::load(tile + (int)pvs[p] * TW + lcol));
       if (a.degV && pe > pb) acc.mul(sdeg[r]);
-      if (col_ok && !(a.debug & 2)) {
-        if (a.debug & 64) acc.store_nt(a.Y + (int64_t)prow[r] * F + col);
+      if (col_ok && !(DBG && (a.debug & 2))) {
+        if (DBG && (a.debug & 64)) acc.store_nt(a.Y + (int64_t)prow[r] * F + col);
         else acc.store(a.Y + (int64_t)prow[r] * F + col);
       }
     }
@@ -604,7 +609,7 @@ static inline int next_pow2(int x) {
 struct Tuning {
   int unroll = 4;        // HG_UNROLL = 4|8      : row loads in flight per lane, pull kernel
   int pipe = 0;          // HG_PIPE = 0|1        : two batches in flight, pull kernel
-  int fused_u = 8;       // HG_FUSED_U = 4|8|16  : row loads in flight per lane, fused kernel
+  int fused_u = 8;       // HG_FUSED_U = 8|16    : row loads in flight per lane, fused kernel
   int fused_small16 = 1; // HG_FUSED_SMALL16=0   : no U = 16 for grids of at most 512 panels
   int fused_persist = 0; // HG_FUSED_PERSIST=1   : persistent kernel with a loader wave
   int fused_fast = 1;    // HG_FUSED_FAST=0      : global loads instead of buffer loads
@@ -617,7 +622,7 @@ static const Tuning &tuning() {
     Tuning x;
     if (const char *e = getenv("HG_UNROLL")) x.unroll = atoi(e) == 8 ? 8 : 4;
     if (const char *e = getenv("HG_PIPE")) x.pipe = atoi(e) != 0;
-    if (const char *e = getenv("HG_FUSED_U")) x.fused_u = atoi(e) == 4 ? 4 : (atoi(e) == 16 ? 16 : 8);
+    if (const char *e = getenv("HG_FUSED_U")) x.fused_u = atoi(e) == 16 ? 16 : 8;
     if (const char *e = getenv("HG_FUSED_SMALL16")) x.fused_small16 = atoi(e) != 0;
     if (const char *e = getenv("HG_FUSED_PERSIST")) x.fused_persist = atoi(e) != 0;
     if (const char *e = getenv("HG_FUSED_FAST")) x.fused_fast = atoi(e) != 0;
@@ -718,21 +723,36 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
     const bool fast = t.fused_fast && a.x_bytes > 0 && a.nrows_x < (1 << 24) && a.F < (1 << 22) &&
                       (!a.Xe_mat || a.mat_bytes > 0);
     if (fast) {
+      if (t.fused_debug) {  // ablation / stamp run: everything kept at run time
+        hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 8, true, true, true, true>), grid, dim3(256), lds_p, stream, ad);
+        return hipGetLastError();
+      }
       // A grid that does not even fill the chip once is latency-bound, not occupancy-bound:
       // put every row gather of a group in flight at once (U = 16) instead of two batches.
-      if (t.fused_u == 16 || (t.fused_small16 && a.npanels <= 512))
-        hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 16, true>), grid, dim3(256), lds_p, stream, ad);
-      else if (t.fused_u == 4)
-        hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 4, true>), grid, dim3(256), lds_p, stream, ad);
-      else
-        hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 8, true>), grid, dim3(256), lds_p, stream, ad);
+      const bool u16 = t.fused_u == 16 || (t.fused_small16 && a.npanels <= 512);
+      const int spec = (a.Xe_mat ? 1 : 0) | ((a.degE || a.W) ? 2 : 0);
+#define HG_PK(UU, M, S) \
+  hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, UU, true, M, S, false>), grid, dim3(256), lds_p, stream, ad)
+      if (u16) {
+        switch (spec) {
+          case 0: HG_PK(16, false, false); break;
+          case 1: HG_PK(16, true, false); break;
+          case 2: HG_PK(16, false, true); break;
+          default: HG_PK(16, true, true); break;
+        }
+      } else {
+        switch (spec) {
+          case 0: HG_PK(8, false, false); break;
+          case 1: HG_PK(8, true, false); break;
+          case 2: HG_PK(8, false, true); break;
+          default: HG_PK(8, true, true); break;
+        }
+      }
+#undef HG_PK
       return hipGetLastError();
     }
   }
-  if (t.fused_u == 4)
-    hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 4, false>), grid, dim3(256), lds_p, stream, ad);
-  else
-    hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 8, false>), grid, dim3(256), lds_p, stream, ad);
+  hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 8, false, true, true, true>), grid, dim3(256), lds_p, stream, ad);
   return hipGetLastError();
 }
 
