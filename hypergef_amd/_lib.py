@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhgaggr.so")
+# HG_AGGR_LIB: another build of the same library (A/B measurements on one box)
+LIB_PATH = os.environ.get("HG_AGGR_LIB") or os.path.join(_HERE, "lib", "libhgaggr.so")
 
 HG_OK = 0
 HG_VARIANT_AUTO = 0

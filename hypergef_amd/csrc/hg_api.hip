@@ -641,6 +641,7 @@ int hg_aggr_fused_f32(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
     a.xcd_remap = (plan->opts.flags & HG_PLAN_NO_XCD_REMAP) ? 0 : 1;
     a.rec = f->d_rec;
     a.rec_tab = f->d_rec_tab;
+    a.eid_all = f->d_eid_all;
     a.max_rec_words = f->max_rec_words;
     a.ng = f->ng;
     a.counters = reinterpret_cast<int32_t *>(ws + c.ctr);

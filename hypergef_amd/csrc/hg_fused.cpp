@@ -12,7 +12,7 @@
 
 namespace hg {
 
-void pack_records(FusedSched &f, int32_t ng);
+void pack_records(FusedSched &f, int32_t ng, int32_t idle);
 
 void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_t,
                  const int32_t *ptr_v, const int32_t *ind_v, const Opts &o, int32_t cap,
@@ -172,7 +172,7 @@ void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_
   }
   close_panel();
   f.pmem_entries = (int64_t)f.pmem.size();
-  pack_records(f, ng);
+  pack_records(f, ng, N);
 }
 
 // One self-contained int32 record per panel for the packed kernel: a header, the
@@ -180,15 +180,18 @@ void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_
 // the `ng` lane groups with longest-first greedy packing, so every group walks
 // the same number of steps and the loop is wave-uniform), then the hop-2 lists.
 //   header  : [0] steps  [1] nrows  [2] nslots  [3] nvs
-//             [4] off_gbase [5] off_stream [6] off_pend [7] off_prow [8] off_eid [9] off_pvs
+//             [4] off_gbase [5] off_stream [6] off_pend [7] off_prow [9] off_pvs
 //   gbase   : ng words, first slot id of each group (a group's slots are numbered in
 //             the order it finishes them)
-//   stream  : steps * ng words; -1 = idle step, else bits 0..29 row index,
-//             bit 30 = row of the materialised table, bit 31 = last entry of its slot
-//   pend    : nrows local end offsets into pvs;  prow: nrows vertex ids
-//   eid     : nslots hyperedge ids in slot order (-1 = materialised, already scaled)
+//   stream  : steps * ng words; `idle` (= N, one past the last row of X, no flags) = idle
+//             step, else bits 0..29 row index, bit 30 = row of the materialised table,
+//             bit 31 = last entry of its slot
+//   prow    : nrows vertex ids
+//   pend    : nrows local end offsets into pvs, two 16-bit values per word
 //   pvs     : nvs slot ids, two 16-bit values per word
-void pack_records(FusedSched &f, int32_t ng) {
+// The hyperedge id of every slot (-1 = materialised, already scaled) goes to eid_all in
+// record order, outside the records: only unbound scaling reads it.
+void pack_records(FusedSched &f, int32_t ng, int32_t idle) {
   f.ng = ng;
   f.rec.clear();
   f.rec_tab.clear();
@@ -220,7 +223,7 @@ void pack_records(FusedSched &f, int32_t ng) {
     // slot ids in (group, completion order); streams
     newid.assign((size_t)pn.nslots, 0);
     gslots.assign((size_t)ng, 0);
-    stream.assign((size_t)steps * ng, -1);
+    stream.assign((size_t)steps * ng, idle);
     int32_t next = 0;
     std::vector<int32_t> eid((size_t)pn.nslots);
     for (int32_t g = 0; g < ng; g++) {
@@ -240,15 +243,14 @@ void pack_records(FusedSched &f, int32_t ng) {
       }
     }
     const int32_t hdr = 16;
-    const int32_t off_gbase = hdr, off_stream = off_gbase + ng, off_pend = off_stream + steps * ng;
-    const int32_t off_prow = off_pend + pn.nrows, off_eid = off_prow + pn.nrows;
-    const int32_t off_pvs = off_eid + pn.nslots;
+    const int32_t off_gbase = hdr, off_stream = off_gbase + ng, off_prow = off_stream + steps * ng;
+    const int32_t off_pend = off_prow + pn.nrows, off_pvs = off_pend + (pn.nrows + 1) / 2;
     const int32_t words = (off_pvs + (pn.nvs + 1) / 2 + 3) & ~3;  // whole 16-byte units
     FRec rt;
     rt.off = (int64_t)f.rec.size();
     rt.len = words;
     rt.off_prow = off_prow;
-    rt.off_eid = off_eid;
+    rt.pad = 0;
     rt.nrows = pn.nrows;
     rt.nslots = pn.nslots;
     rt.slot_base = (int32_t)f.eid_all.size();
@@ -269,15 +271,14 @@ void pack_records(FusedSched &f, int32_t ng) {
     r[5] = off_stream;
     r[6] = off_pend;
     r[7] = off_prow;
-    r[8] = off_eid;
     r[9] = off_pvs;
     for (int32_t g = 0; g < ng; g++) r[off_gbase + g] = gslots[g];
     std::copy(stream.begin(), stream.end(), r + off_stream);
+    uint16_t *pe = reinterpret_cast<uint16_t *>(r + off_pend);
     for (int32_t i = 0; i < pn.nrows; i++) {
-      r[off_pend + i] = f.pend[pn.r0 + i];
+      pe[i] = (uint16_t)f.pend[pn.r0 + i];  // <= vslot_cap
       r[off_prow + i] = f.prow[pn.r0 + i];
     }
-    for (int32_t k = 0; k < pn.nslots; k++) r[off_eid + k] = eid[k];
     uint16_t *pv = reinterpret_cast<uint16_t *>(r + off_pvs);
     for (int32_t i = 0; i < pn.nvs; i++) pv[i] = (uint16_t)newid[f.pvs[pn.v0 + i]];
   }

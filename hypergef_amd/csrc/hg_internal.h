@@ -57,7 +57,7 @@ struct FPanel {
 struct FRec {
   int64_t off;  // word offset of the panel's record
   int32_t len;  // record length in words
-  int32_t off_prow, off_eid;  // where the vertex ids / hyperedge ids sit inside the record
+  int32_t off_prow, pad;  // where the vertex ids sit inside the record
   int32_t nrows, nslots;
   int32_t slot_base, row_base;  // position of this panel's slots / rows in the bound scale arrays
 };

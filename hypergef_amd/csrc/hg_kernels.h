@@ -30,6 +30,7 @@ struct FusedArgs {
   int32_t npanels;
   const int32_t *rec;     // packed per-panel records (hg_fused.cpp, pack_records)
   const FRec *rec_tab;    // per panel: record offset / length / list positions
+  const int32_t *eid_all; // hyperedge id of every slot, record order (-1: materialised)
   int32_t max_rec_words;  // LDS space for one record
   int32_t ng;             // lane groups the records were packed for
   int32_t cap, rows_cap;  // LDS tile rows (hyperedge slots) and rows per panel

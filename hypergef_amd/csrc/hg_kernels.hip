@@ -10,6 +10,8 @@
 
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "hg_kernels.h"
 
 namespace hg {
@@ -256,7 +258,8 @@ __device__ __forceinline__ void lds_barrier() {
 // stages it, and hop 1 is a wave-uniform loop over a [step][group] entry stream in
 // which the panel's hyperedge slots were packed longest-first over the lane
 // groups -- no per-group offsets to look up, no divergent trip counts, the same
-// number of row gathers for every group.  Entry word: -1 idle, else bits 0..29 =
+// number of row gathers for every group.  Entry word: N (one past the last row of
+// X, no flags) = idle, else bits 0..29 =
 // row, bit 30 = row of the materialised table, bit 31 = last member of its slot
 // (scale, store to the LDS tile, start the next slot).  Members of a slot stay in
 // their CSR order, so the arithmetic is still the CPU reference's.
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
         sA[i] = a.bsA[rt.slot_base + i];
         sB[i] = a.bsB[rt.slot_base + i];
       } else {
-        const int e = grec[rt.off_eid + i];  // -1: materialised row, already scaled
+        const int e = a.eid_all[rt.slot_base + i];  // -1: materialised row, already scaled
         sA[i] = (a.degE && e >= 0) ? a.degE[e] : 1.f;
         sB[i] = (a.W && e >= 0) ? a.W[e] : 1.f;
       }
@@ -327,39 +330,55 @@ __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
   const int steps = rec[0], nrows = rec[1];
   const int32_t *gbase = rec + rec[4];
   const int32_t *stream = rec + rec[5];
-  const int32_t *pend = rec + rec[6];
+  const uint16_t *pend = reinterpret_cast<const uint16_t *>(rec + rec[6]);
   const int32_t *prow = rec + rec[7];
   const uint16_t *pvs = reinterpret_cast<const uint16_t *>(rec + rec[9]);
 
   const int g = tid / LPR;
   if (!(DBG && (a.debug & 4))) {  // ---- hop 1
-    int slot = gbase[g];
+    [[maybe_unused]] int slot = gbase[g];
+    float *tp = tile + gbase[g] * TW + lcol;  // where this group's next finished slot goes
     V acc = V::zero();
-    [[maybe_unused]] const unsigned row_bytes = (unsigned)a.F * 4u, col_bytes = (unsigned)col * 4u;
+    // FAST: nothing in the gather is predicated.  An idle entry names row N, one past the
+    // table, and a lane whose columns lie beyond F gets bit 31 in its column offset: both
+    // byte offsets fall outside the descriptor's range (tables are < 2 GiB here), and an
+    // out-of-range buffer load returns zeros without touching memory.
+    [[maybe_unused]] const unsigned row_bytes = (unsigned)a.F * 4u;
+    [[maybe_unused]] const unsigned col_off = col_ok ? (unsigned)col * 4u : 0x80000000u;
     [[maybe_unused]] __amdgpu_buffer_rsrc_t rx, rm;
     if constexpr (FAST) {
-      rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.X), 0, a.x_bytes, 0x00020000);
+      const bool no_x = DBG && (a.debug & 1);  // ablation: an empty range turns every load into zeros
+      rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.X), 0, no_x ? 0 : a.x_bytes, 0x00020000);
       rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.Xe_mat ? a.Xe_mat : a.X), 0,
-                                             a.Xe_mat ? a.mat_bytes : 0, 0x00020000);
+                                             (a.Xe_mat && !no_x) ? a.mat_bytes : 0, 0x00020000);
     }
-    for (int s0 = 0; s0 < steps; s0 += U) {
+    const int idle = a.nrows_x;
+    // FULL: all U steps of the block exist, so the entry reads need no bounds test.
+    auto block = [&](const int s0, auto full) {
+      constexpr bool FULL = decltype(full)::value;
       int ent[U];
 #pragma unroll
-      for (int j = 0; j < U; j++) ent[j] = (s0 + j < steps) ? stream[(s0 + j) * NG + g] : -1;
+      for (int j = 0; j < U; j++) ent[j] = (FULL || s0 + j < steps) ? stream[(s0 + j) * NG + g] : idle;
       V v[U];
 #pragma unroll
       for (int j = 0; j < U; j++) {
-        const bool on = col_ok && ent[j] != -1 && !(DBG && (a.debug & 1));
+        if (!FULL && s0 + j >= steps) {  // wave-uniform: no load is issued for a step that is not there
+          v[j] = V::zero();
+          continue;
+        }
         if constexpr (FAST) {
-          const unsigned off = __umul24((unsigned)ent[j] & 0x3fffffffu, row_bytes) + col_bytes;
-          const bool mat = MAT && (ent[j] & 0x40000000);
-          hg_u4 q = {0u, 0u, 0u, 0u};
-          if (on && !mat) q = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+          const unsigned off = __umul24((unsigned)ent[j], row_bytes) + col_off;  // flags sit above bit 23
+          hg_u4 q;
           if constexpr (MAT) {
-            if (on && mat) q = __builtin_amdgcn_raw_buffer_load_b128(rm, off, 0, 0);
+            const bool mat = (ent[j] & 0x40000000) != 0;
+            q = __builtin_amdgcn_raw_buffer_load_b128(rx, mat ? 0x80000000u : off, 0, 0);
+            if (mat) q = __builtin_amdgcn_raw_buffer_load_b128(rm, off, 0, 0);
+          } else {
+            q = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
           }
           v[j].v = __builtin_bit_cast(float4, q);
         } else {
+          const bool on = col_ok && ent[j] != idle && !(DBG && (a.debug & 1));
           const int64_t idx = ent[j] & 0x3fffffff;
           const float *base = (MAT && a.Xe_mat && (ent[j] & 0x40000000)) ? a.Xe_mat : a.X;
           v[j] = on ? V::load(base + idx * F + col) : V::zero();
@@ -367,18 +386,22 @@ __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
       }
 #pragma unroll
       for (int j = 0; j < U; j++) {
-        acc.add(v[j]);        // an idle step contributed zeros
-        if (ent[j] < -1) {    // bit 31 set and not the idle word: last member of this slot
+        acc.add(v[j]);      // an idle step contributed zeros
+        if (ent[j] < 0) {   // bit 31: last member of this slot
           if constexpr (SCALED) {
             if (a.degE) acc.mul(sA[slot]);
             if (a.W) acc.mul(sB[slot]);
+            slot++;
           }
-          acc.store(tile + slot * TW + lcol);
-          slot++;
+          acc.store(tp);
+          tp += TW;
           acc = V::zero();
         }
       }
-    }
+    };
+    int s0 = 0;
+    for (; s0 + U <= steps; s0 += U) block(s0, std::true_type{});
+    if (s0 < steps) block(s0, std::false_type{});
   }
   HG_STAMP(3);
   __syncthreads();
@@ -400,166 +423,6 @@ __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
   HG_STAMP(5);
 }
 
-// one wave copies n dwords global -> LDS with global_load_lds (64 dwords per instruction;
-// the LDS destination is wave-uniform base + lane * 4 B, the source address is per lane).
-// Sub-dword sizes are not used: a 2-byte global_load_lds does not land 2-byte granules.
-__device__ __forceinline__ void dma_copy_dwords(const int32_t *src, int32_t *dst, int n, int lane) {
-  for (int i0 = 0; i0 < n; i0 += 64) {
-    if (i0 + lane < n)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i0 + lane),
-                                       (__attribute__((address_space(3))) void *)(dst + i0), 4, 0, 0);
-  }
-}
-
-
-// Wave-specialised persistent form of fused_packed_kernel: 4 compute waves + 1
-// loader wave, two record buffers in LDS.  The loader wave draws the next panel of
-// its XCD class from a per-class counter in global memory (dynamic, so the grid
-// may be any size >= what the chip holds), copies that panel's record into the
-// idle buffer by LDS-DMA and gathers its scales, all while the compute waves work
-// on the current buffer: descriptor, record and scale latencies are off the
-// compute waves' critical path, and because a wave's memory counter is its own,
-// the loader's loads never queue ahead of the compute waves' row gathers.
-template <int LPR, int VEC, int U>
-__global__ __launch_bounds__(320) void fused_packed_ws_kernel(const FusedArgs a) {
-  constexpr int CT = 256;
-  constexpr int NG = CT / LPR;
-  constexpr int TW = LPR * VEC;
-  using V = Vec<VEC>;
-  extern __shared__ int32_t smem[];
-  const int tid = threadIdx.x;
-  const bool loader = tid >= CT;
-  const int64_t F = a.F;
-
-  // this workgroup's class of panels (one contiguous eighth per XCD class)
-  int cls, start, end;
-  {
-    const int x = blockIdx.x & 7;
-    const int cpx = a.npanels >> 3, rem = a.npanels & 7;
-    cls = x;
-    start = x * cpx + (x < rem ? x : rem);
-    end = start + cpx + (x < rem ? 1 : 0);
-  }
-
-  float *tile = reinterpret_cast<float *>(smem);  // [cap * TW]
-  const int bufw = a.max_rec_words + 2 * a.cap + a.rows_cap;  // words per buffer
-  int32_t *buf0 = smem + a.cap * TW, *buf1 = buf0 + bufw;
-  const bool weighted = a.degE || a.W || a.degV;
-
-  // loader wave: draw a panel, start copying its record into `buf`; returns the record length
-  // (0 = class exhausted; rec[0] = -1 then tells the compute waves to stop)
-  auto start_load = [&](int32_t *buf, int lane) -> int {
-    int idx = 0;
-    if (lane == 0) idx = atomicAdd(a.counters + cls * 16, 1);
-    idx = __builtin_amdgcn_readfirstlane(idx) + start;
-    if (idx >= end) {
-      if (lane == 0) buf[0] = -1;
-      return 0;
-    }
-    const FRec rt = a.rec_tab[idx];
-    dma_copy_dwords(a.rec + rt.off, buf, rt.len, lane);
-    return rt.len;
-  };
-  auto finish_load = [&](int32_t *buf, int len, int lane) {
-    if (len == 0) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (!weighted) return;
-    const int nrows = buf[1], nslots = buf[2];
-    const int32_t *prow = buf + buf[7];
-    const int32_t *eid = buf + buf[8];
-    float *sA = reinterpret_cast<float *>(buf + a.max_rec_words), *sB = sA + a.cap, *sdeg = sB + a.cap;
-    if (a.degE || a.W)
-      for (int i = lane; i < nslots; i += 64) {
-        const int e = eid[i];
-        sA[i] = (a.degE && e >= 0) ? a.degE[e] : 1.f;
-        sB[i] = (a.W && e >= 0) ? a.W[e] : 1.f;
-      }
-    if (a.degV)
-      for (int i = lane; i < nrows; i += 64) sdeg[i] = a.degV[prow[i]];
-  };
-
-  if (loader) {
-    const int lane = tid - CT;
-    const int len = start_load(buf0, lane);
-    finish_load(buf0, len, lane);
-  }
-  __syncthreads();
-
-  for (int it = 0;; it++) {
-    int32_t *rec = (it & 1) ? buf1 : buf0;
-    int32_t *nxt = (it & 1) ? buf0 : buf1;
-    const int steps = rec[0];
-    if (steps < 0) break;  // same LDS word for every wave: uniform exit
-    HG_STAMP_INIT(!loader);
-    if (loader) {
-      const int lane = tid - CT;
-      const int len = start_load(nxt, lane);
-      lds_barrier();  // (M)
-      finish_load(nxt, len, lane);
-      lds_barrier();  // (X)
-      continue;
-    }
-    const int gl = tid & (LPR - 1);
-    const int lcol = gl * VEC;
-    const int col = blockIdx.y * TW + lcol;
-    const bool col_ok = col < a.F;
-    const int g = tid / LPR;
-    const int nrows = rec[1];
-    const int32_t *gbase = rec + rec[4];
-    const int32_t *stream = rec + rec[5];
-    const int32_t *pend = rec + rec[6];
-    const int32_t *prow = rec + rec[7];
-    const uint16_t *pvs = reinterpret_cast<const uint16_t *>(rec + rec[9]);
-    const float *sA = reinterpret_cast<const float *>(rec + a.max_rec_words), *sB = sA + a.cap, *sdeg = sB + a.cap;
-    {  // ---- hop 1
-      int slot = gbase[g];
-      V acc = V::zero();
-      for (int s0 = 0; s0 < steps; s0 += U) {
-        int ent[U];
-#pragma unroll
-        for (int j = 0; j < U; j++) ent[j] = (s0 + j < steps) ? stream[(s0 + j) * NG + g] : -1;
-        V v[U];
-#pragma unroll
-        for (int j = 0; j < U; j++) {
-          const bool on = col_ok && ent[j] != -1 && !(a.debug & 1);
-          const int64_t idx = ent[j] & 0x3fffffff;
-          const float *base = (a.Xe_mat && (ent[j] & 0x40000000)) ? a.Xe_mat : a.X;
-          v[j] = on ? V::load(base + idx * F + col) : V::zero();
-        }
-#pragma unroll
-        for (int j = 0; j < U; j++) {
-          if (ent[j] != -1) {
-            acc.add(v[j]);
-            if (ent[j] < 0) {
-              if (a.degE) acc.mul(sA[slot]);
-              if (a.W) acc.mul(sB[slot]);
-              acc.store(tile + slot * TW + lcol);
-              slot++;
-              acc = V::zero();
-            }
-          }
-        }
-      }
-    }
-    HG_STAMP(1);
-    lds_barrier();  // (M)
-    HG_STAMP(2);
-    {  // ---- hop 2
-      const int rpg = (nrows + NG - 1) / NG;
-      const int r0 = min(g * rpg, nrows), r1 = min(r0 + rpg, nrows);
-      for (int r = r0; r < r1; r++) {
-        V acc = V::zero();
-        const int pb = r ? pend[r - 1] : 0, pe = pend[r];
-        for (int p = pb; p < pe; p++) acc.add(V::load(tile + (int)pvs[p] * TW + lcol));
-        if (a.degV && pe > pb) acc.mul(sdeg[r]);
-        if (col_ok && !(a.debug & 2)) acc.store(a.Y + (int64_t)prow[r] * F + col);
-      }
-    }
-    HG_STAMP(3);
-    lds_barrier();  // (X): the Y stores stay in flight across it
-    HG_STAMP(4);
-  }
-}
 
 // The reference's register-fused scheme on wave64: LPR lanes = LPR feature
 // columns of one task, 64/LPR tasks per wave.  Gather-sum the read partition,
@@ -611,10 +474,8 @@ struct Tuning {
   int pipe = 0;          // HG_PIPE = 0|1        : two batches in flight, pull kernel
   int fused_u = 8;       // HG_FUSED_U = 8|16    : row loads in flight per lane, fused kernel
   int fused_small16 = 1; // HG_FUSED_SMALL16=0   : no U = 16 for grids of at most 512 panels
-  int fused_persist = 0; // HG_FUSED_PERSIST=1   : persistent kernel with a loader wave
   int fused_fast = 1;    // HG_FUSED_FAST=0      : global loads instead of buffer loads
   int fused_coltile = 0; // HG_FUSED_COLTILE=1   : 128-byte column tiles for wide rows
-  int fused_grid = 0;    // HG_FUSED_GRID=n      : workgroups of the persistent kernel
   int fused_debug = 0;   // HG_FUSED_DEBUG=bits  : ablation / stamp switches (timing only)
 };
 static const Tuning &tuning() {
@@ -624,10 +485,8 @@ static const Tuning &tuning() {
     if (const char *e = getenv("HG_PIPE")) x.pipe = atoi(e) != 0;
     if (const char *e = getenv("HG_FUSED_U")) x.fused_u = atoi(e) == 16 ? 16 : 8;
     if (const char *e = getenv("HG_FUSED_SMALL16")) x.fused_small16 = atoi(e) != 0;
-    if (const char *e = getenv("HG_FUSED_PERSIST")) x.fused_persist = atoi(e) != 0;
     if (const char *e = getenv("HG_FUSED_FAST")) x.fused_fast = atoi(e) != 0;
     if (const char *e = getenv("HG_FUSED_COLTILE")) x.fused_coltile = atoi(e) != 0;
-    if (const char *e = getenv("HG_FUSED_GRID")) x.fused_grid = atoi(e);
     if (const char *e = getenv("HG_FUSED_DEBUG")) x.fused_debug = atoi(e);
     return x;
   }();
@@ -692,30 +551,6 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
   const Tuning &t = tuning();
   FusedArgs ad = a;
   ad.debug = t.fused_debug;
-  if (t.fused_persist) {
-    // persistent + loader wave; work is drawn from per-class counters, so any grid that
-    // covers the chip works (surplus workgroups find their class empty and leave)
-    static int num_cu = 0;
-    if (num_cu == 0) {
-      int dev = 0;
-      if (hipGetDevice(&dev) != hipSuccess ||
-          hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || num_cu <= 0)
-        num_cu = 256;
-    }
-    const size_t bufw = (size_t)a.max_rec_words + 2 * a.cap + a.rows_cap;
-    const size_t lds_w = (size_t)a.cap * TW * 4 + 2 * bufw * 4 + 16;
-    hipError_t e = hipMemsetAsync(a.counters, 0, 512, stream);
-    if (e != hipSuccess) return e;
-    int per_cu = (int)std::min<size_t>(6, (160 * 1024) / (lds_w + 256));
-    if (per_cu < 1) per_cu = 1;
-    const int want = t.fused_grid > 0 ? t.fused_grid : num_cu * per_cu;
-    const int nwg = std::max(8, std::min((a.npanels + 7) / 8 * 8, want));
-    if (t.fused_u == 8)
-      hipLaunchKernelGGL((fused_packed_ws_kernel<LPR, VEC, 8>), dim3(nwg, col_tiles), dim3(320), lds_w, stream, ad);
-    else
-      hipLaunchKernelGGL((fused_packed_ws_kernel<LPR, VEC, 4>), dim3(nwg, col_tiles), dim3(320), lds_w, stream, ad);
-    return hipGetLastError();
-  }
   const dim3 grid(a.npanels, col_tiles);
   const size_t lds_p = (size_t)a.cap * TW * 4 + (size_t)a.max_rec_words * 4 +
                        (size_t)(2 * a.cap + a.rows_cap) * 4 + 16;
