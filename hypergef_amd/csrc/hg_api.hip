@@ -234,7 +234,7 @@ int run_sched(const hg_plan *p, const hg::Sched &s, int32_t F, const int32_t *pt
   a.panel_nnz = p->opts.panel_nnz;
   a.xcd_remap = (p->opts.flags & HG_PLAN_NO_XCD_REMAP) ? 0 : 1;
   const bool vec4 = (F % 4 == 0) && aligned16(src) && aligned16(dst) && aligned16(partial);
-  hipError_t e = hg::launch_gather(a, (int)s.fixups.size(), s.d_fixups, vec4, stream);
+  hipError_t e = hg::launch_gather(a, (int)s.fixups.size(), s.n_fix_l1, s.d_fixups, vec4, stream);
   if (e != hipSuccess) return hip_fail("gather_rows launch", e);
   return HG_OK;
 }

@@ -24,6 +24,7 @@ struct Task {
 };
 
 // A row split over several tasks: out[row] = scale * sum_{k<count} partial[first+k].
+// pad > 0: first-level fixup of a two-level sum, partial[pad-1] = that sum, unscaled.
 struct Fixup {
   int32_t row, first, count, pad;
 };
@@ -34,7 +35,8 @@ struct Sched {
   int32_t max_len = 0;
   std::vector<Panel> panels;
   std::vector<Task> tasks;
-  std::vector<Fixup> fixups;
+  std::vector<Fixup> fixups;  // first-level fixups [0, n_fix_l1), then the final ones
+  int32_t n_fix_l1 = 0;
   int32_t nslots = 0;
   // device copies
   Panel *d_panels = nullptr;

@@ -55,7 +55,7 @@ struct PushArgs {
   int32_t F;
 };
 
-hipError_t launch_gather(const GatherArgs &a, int nfix, const Fixup *fixups, bool vec4,
+hipError_t launch_gather(const GatherArgs &a, int nfix, int nfix_l1, const Fixup *fixups, bool vec4,
                          hipStream_t stream);
 hipError_t launch_fused(const FusedArgs &a, bool vec4, hipStream_t stream);
 int fused_tile_row_floats(int F, bool vec4);

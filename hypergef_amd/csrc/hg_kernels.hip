@@ -204,7 +204,8 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const GatherArgs a) {
   }
 }
 
-// out[row,:] = scaleB * (scaleA * sum_k partial[first+k,:]), slots in order.
+// out[row,:] = scaleB * (scaleA * sum_k partial[first+k,:]), slots in order; a first-level
+// fixup (pad > 0) leaves its unscaled sum in partial[pad-1] for the final one.
 template <int LPR, int VEC>
 __global__ __launch_bounds__(256) void fixup_rows_kernel(const GatherArgs a, const Fixup *fixups,
                                                          int nfix) {
@@ -216,8 +217,21 @@ __global__ __launch_bounds__(256) void fixup_rows_kernel(const GatherArgs a, con
   if (f >= nfix || col >= a.F) return;
   const Fixup fx = fixups[f];
   const int64_t F = a.F;
+  const float *src = a.partial + (int64_t)fx.first * F + col;
   V acc = V::zero();
-  for (int k = 0; k < fx.count; k++) acc.add(V::load(a.partial + (int64_t)(fx.first + k) * F + col));
+  int k = 0;
+  for (; k + 4 <= fx.count; k += 4) {  // four slot loads in flight, added in slot order
+    V v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = V::load(src + (int64_t)(k + j) * F);
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc.add(v[j]);
+  }
+  for (; k < fx.count; k++) acc.add(V::load(src + (int64_t)k * F));
+  if (fx.pad > 0) {
+    acc.store(a.partial + (int64_t)(fx.pad - 1) * F + col);
+    return;
+  }
   const int srow = a.scale_map ? a.scale_map[fx.row] : fx.row;
   const int64_t drow = a.dst_map ? a.dst_map[fx.row] : fx.row;
   if (a.scaleA) acc.mul(a.scaleA[srow]);
@@ -494,7 +508,7 @@ static const Tuning &tuning() {
 }
 
 template <int LPR, int VEC>
-static hipError_t launch_gather_t(const GatherArgs &a, int nfix, const Fixup *fixups,
+static hipError_t launch_gather_t(const GatherArgs &a, int nfix, int nfix_l1, const Fixup *fixups,
                                   hipStream_t stream) {
   const int col_tiles = (a.F + LPR * VEC - 1) / (LPR * VEC);
   const int nblocks = a.n_task_blocks + a.npanels;
@@ -512,23 +526,25 @@ static hipError_t launch_gather_t(const GatherArgs &a, int nfix, const Fixup *fi
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
-  if (nfix > 0) {
-    const int per_block = 256 / LPR;
-    hipLaunchKernelGGL((fixup_rows_kernel<LPR, VEC>), dim3((nfix + per_block - 1) / per_block, col_tiles),
-                       dim3(256), 0, stream, a, fixups, nfix);
-    return hipGetLastError();
-  }
-  return hipSuccess;
+  const int per_block = 256 / LPR;
+  if (nfix_l1 > 0)  // first level of the two-level sums (rows cut into very many tasks)
+    hipLaunchKernelGGL((fixup_rows_kernel<LPR, VEC>), dim3((nfix_l1 + per_block - 1) / per_block, col_tiles),
+                       dim3(256), 0, stream, a, fixups, nfix_l1);
+  if (nfix > nfix_l1)
+    hipLaunchKernelGGL((fixup_rows_kernel<LPR, VEC>),
+                       dim3((nfix - nfix_l1 + per_block - 1) / per_block, col_tiles), dim3(256), 0, stream, a,
+                       fixups + nfix_l1, nfix - nfix_l1);
+  return hipGetLastError();
 }
 
-hipError_t launch_gather(const GatherArgs &a, int nfix, const Fixup *fixups, bool vec4,
+hipError_t launch_gather(const GatherArgs &a, int nfix, int nfix_l1, const Fixup *fixups, bool vec4,
                          hipStream_t stream) {
   const int lanes = vec4 ? a.F / 4 : a.F;
   const int lpr = std::min(64, next_pow2(std::max(lanes, 1)));
 #define HG_CASE(L)                                                        \
   case L:                                                                 \
-    return vec4 ? launch_gather_t<L, 4>(a, nfix, fixups, stream)          \
-                : launch_gather_t<L, 1>(a, nfix, fixups, stream);
+    return vec4 ? launch_gather_t<L, 4>(a, nfix, nfix_l1, fixups, stream) \
+                : launch_gather_t<L, 1>(a, nfix, nfix_l1, fixups, stream);
   switch (lpr) {
     HG_CASE(1)
     HG_CASE(2)

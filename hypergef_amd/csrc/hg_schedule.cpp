@@ -124,7 +124,11 @@ void transpose_csr(int32_t nrows, int32_t ncols, const int32_t *ptr,
 //  * a row longer than short_max ends the running panel and becomes
 //    ceil(len/split_len) wave tasks; with more than one task the row gets
 //    partial-sum slots and a fixup record (summed in slot order, so the result
-//    does not depend on scheduling).
+//    does not depend on scheduling).  A row cut into more than kFixupFan tasks is
+//    summed in two levels: ~sqrt(tasks) first-level fixups, each adding a run of
+//    slots into a slot of its own (Fixup::pad = that slot + 1), then the final
+//    fixup over those -- a hub row of 10^6 entries is not one serial chain of
+//    thousands of dependent loads.  First-level fixups come first in the list.
 void build_sched(int32_t nrows, const int32_t *ptr, const Opts &o, Sched &s) {
   s.nrows = nrows;
   s.max_len = 0;
@@ -132,6 +136,9 @@ void build_sched(int32_t nrows, const int32_t *ptr, const Opts &o, Sched &s) {
   s.tasks.clear();
   s.fixups.clear();
   s.nslots = 0;
+  s.n_fix_l1 = 0;
+  constexpr int32_t kFixupFan = 32;
+  std::vector<Fixup> finals;
   int32_t start = 0;
   auto close = [&](int32_t end_row) {
     if (end_row > start) {
@@ -153,11 +160,21 @@ void build_sched(int32_t nrows, const int32_t *ptr, const Opts &o, Sched &s) {
       if (chunks == 1) {
         s.tasks.push_back(Task{r, ptr[r], ptr[r + 1], -1});
       } else {
-        s.fixups.push_back(Fixup{r, s.nslots, chunks, 0});
+        const int32_t first = s.nslots;
         for (int32_t c = 0; c < chunks; c++) {
           const int32_t b = ptr[r] + c * o.split_len;
           const int32_t e = std::min(b + o.split_len, ptr[r + 1]);
           s.tasks.push_back(Task{r, b, e, s.nslots++});
+        }
+        if (chunks <= kFixupFan) {
+          finals.push_back(Fixup{r, first, chunks, 0});
+        } else {
+          int32_t fan = 1;
+          while (fan * fan < chunks) fan++;
+          const int32_t groups = (chunks + fan - 1) / fan;
+          finals.push_back(Fixup{r, s.nslots, groups, 0});
+          for (int32_t g = 0; g < groups; g++)
+            s.fixups.push_back(Fixup{r, first + g * fan, std::min(fan, chunks - g * fan), ++s.nslots});
         }
       }
     } else if (r - start == o.panel_rows ||
@@ -167,6 +184,8 @@ void build_sched(int32_t nrows, const int32_t *ptr, const Opts &o, Sched &s) {
     }
   }
   close(nrows);
+  s.n_fix_l1 = (int32_t)s.fixups.size();
+  s.fixups.insert(s.fixups.end(), finals.begin(), finals.end());
   // longest tasks first: the tail of the launch is made of short work
   std::stable_sort(s.tasks.begin(), s.tasks.end(), [](const Task &a, const Task &b) {
     return (a.end - a.beg) > (b.end - b.beg);

@@ -157,6 +157,28 @@ def test_split_rows_and_edge_cases(hg, oracle):
                 _assert_close(Y, ref)
 
 
+def test_hub_row_two_level_sum(hg, oracle):
+    """A vertex that belongs to every hyperedge: its row is cut into hundreds of wave tasks and
+    summed by two levels of fixups (and is a hub of the fused schedule)."""
+    from hypergef_amd.plan import Plan, make_opts
+    rng = np.random.default_rng(5)
+    N, M = 3000, 5000
+    rows = [np.unique(np.concatenate([[0], rng.integers(1, N, rng.integers(1, 6))])) for _ in range(M)]
+    csrptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    inc = synth.Incidence(N, M, csrptr, np.concatenate(rows).astype(np.int32), name="hub")
+    F = 32
+    X, degE, degV, W, H_ptr, H_ind = _inputs(inc, F, oracle, seed=6)
+    ref = oracle.hgnn_check(inc.N, inc.M, F, H_ptr, H_ind, inc.csrptr, inc.colind, X, degE, degV, W)
+    ptr, ind = _dev(inc.csrptr), _dev(inc.colind)
+    for opts in (None, make_opts(short_max=4, split_len=8, panel_rows=16, panel_nnz=64)):
+        plan = Plan.from_tensors(inc.N, ptr, ind, opts)
+        lvl1 = plan.schedule(1)["fixups"][:, 3] > 0
+        assert bool(lvl1.any()) == (opts is not None)  # 5000 entries: 10 tasks by default, 625 with split_len 8
+        for variant in ("pull", "fused"):
+            Y = plan.aggregate(ptr, ind, _dev(X), _dev(degE.ravel()), _dev(degV.ravel()), _dev(W), variant=variant)
+            _assert_close(Y, ref)
+
+
 def test_degenerate_graphs(hg):
     from hypergef_amd.plan import Plan
     # no hyperedges at all: Y = 0

@@ -83,17 +83,29 @@ def _emulate(plan_sched, ptr, ind, src, scaleA, scaleB, F):
             written[row] += 1
         else:
             partial[slot] = acc
-    for row, first, count, _ in plan_sched["fixups"]:
+    for row, first, count, out in plan_sched["fixups"]:  # first-level fixups come first
         acc = np.zeros(F, np.float32)
         for k in range(count):
             acc = acc + partial[first + k]
+        if out > 0:  # two-level sum: this run of slots goes to a slot of its own
+            partial[out - 1] = acc
+            continue
         dst[row] = scale(row, acc)
         written[row] += 1
     assert np.all(written == 1), "every row must be produced exactly once"
     return dst
 
 
-@pytest.mark.parametrize("case", ["cora", "pubmed", "ragged_split", "tiny_panels"])
+def _hub_incidence(N=300, M=260, seed=5):
+    """Vertex 0 belongs to every hyperedge: its row of H is cut into far more tasks than one
+    fixup sums, so the schedule must use the two-level form."""
+    rng = np.random.default_rng(seed)
+    rows = [np.unique(np.concatenate([[0], rng.integers(1, N, rng.integers(1, 6))])) for _ in range(M)]
+    ptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    return synth.Incidence(N, M, ptr, np.concatenate(rows).astype(np.int32), name="hub")
+
+
+@pytest.mark.parametrize("case", ["cora", "pubmed", "ragged_split", "tiny_panels", "two_level"])
 def test_plan_schedule_covers_and_reproduces_oracle(hg, oracle, case):
     from hypergef_amd import plan as planmod
     if case == "cora":
@@ -103,6 +115,9 @@ def test_plan_schedule_covers_and_reproduces_oracle(hg, oracle, case):
     elif case == "ragged_split":  # long rows cut into several tasks + fixups, empty hyperedges
         inc = synth.random_incidence(400, 150, 14.0, seed=4, empty_frac=0.15)
         opts = planmod.make_opts(short_max=6, split_len=8, panel_rows=16, panel_nnz=32, host_only=True)
+    elif case == "two_level":
+        inc = _hub_incidence()
+        opts = planmod.make_opts(short_max=4, split_len=4, panel_rows=16, panel_nnz=32, host_only=True)
     else:
         inc = synth.random_incidence(97, 211, 2.5, seed=8, empty_frac=0.3)
         opts = planmod.make_opts(short_max=4, split_len=4, panel_rows=3, panel_nnz=7, host_only=True)
@@ -128,6 +143,11 @@ def test_plan_schedule_covers_and_reproduces_oracle(hg, oracle, case):
             tl = s["tasks"][:, 2] - s["tasks"][:, 1]
             assert tl.max() <= info["split_len"] and np.all(np.diff(tl) <= 0)  # longest first
         assert info["partials"][hop] == (s["fixups"][:, 2].sum() if len(s["fixups"]) else 0)
+        if len(s["fixups"]):
+            lvl1 = s["fixups"][:, 3] > 0
+            assert s["fixups"][:, 2].max() <= 32  # no serial chain longer than the fan-in
+            assert not np.any(np.diff(lvl1.astype(np.int8)) > 0)  # first-level fixups come first
+            assert (case == "two_level" and hop == 1) == bool(lvl1.any())
     Xe = _emulate(s0, inc.csrptr, inc.colind, X, degE.ravel(), W, F)
     Y = _emulate(s1, H_ptr, H_ind, Xe, degV.ravel(), None, F)
     Yref, Xe_ref = oracle.hgnn_check(inc.N, inc.M, F, H_ptr, H_ind, inc.csrptr, inc.colind, X,
