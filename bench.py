@@ -251,6 +251,16 @@ def main():
     }
 
     if not args.no_extras:
+        # What a plain device copy X -> Y (the 2NF term of B_alg, no gather, no index traffic)
+        # takes on this box: the practical floor of any kernel that reads X and writes Y once.
+        for _ in range(5):
+            Y.copy_(X)
+        _, d = timed_steps(lambda: Y.copy_(X), 50, sync, lambda: None)
+        copy_s = d / 50
+        out["device_copy"] = {"ms": copy_s * 1e3, "gbs": 2.0 * inc.N * F * 4 / copy_s / 1e9,
+                              "step_over_copy": (wall / args.steps) / copy_s,
+                              "note": "torch copy of X into Y, same buffers; step_over_copy = "
+                                      "aggregation step time / this"}
         # latency of ONE hypergraph (what result.xlsx "fig7,fig9" reports, ms per aggregation)
         if args.shape != "powerlaw":
             p1 = torch.from_numpy(base.csrptr).to(dev)

@@ -17,6 +17,7 @@ HG_VARIANT_PUSH_ATOMIC = 2
 HG_VARIANT_FUSED = 3
 HG_PLAN_HOST_ONLY = 1
 HG_PLAN_NO_XCD_REMAP = 2
+HG_PLAN_DFS_ORDER = 4
 
 VARIANTS = {"auto": HG_VARIANT_AUTO, "pull": HG_VARIANT_PULL, "push_atomic": HG_VARIANT_PUSH_ATOMIC,
             "fused": HG_VARIANT_FUSED}

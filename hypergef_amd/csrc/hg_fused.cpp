@@ -108,7 +108,7 @@ void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_
     }
   }
 
-  // fused panels over that order
+  // fused panels
   std::vector<int32_t> stamp((size_t)M, -1), slot_of((size_t)M, 0);
   FPanel cur{};
   auto open_panel = [&]() {
@@ -130,8 +130,43 @@ void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_
       f.soff.pop_back();  // the opening 0 of an empty panel
     }
   };
+  // Rows are taken greedily: after a vertex joins the panel, the vertices that share the
+  // panel's recomputed hyperedges become candidates, and the next row is the candidate with
+  // the largest share of its own hyperedges already in the panel (ties: most shared) -- it
+  // adds the fewest new slots and member gathers per row.  The vertex that no longer fits
+  // opens the next panel, so neighbouring panels also share rows of X in L2.  With no
+  // candidate left, the depth-first order above supplies the next vertex.
+  struct Cand {
+    float frac;
+    int32_t shared, v;
+    bool operator<(const Cand &o) const {
+      return frac != o.frac ? frac < o.frac : (shared != o.shared ? shared < o.shared : v > o.v);
+    }
+  };
+  const bool greedy = !(o.flags & HG_PLAN_DFS_ORDER);
+  std::vector<Cand> heap;
+  std::vector<int32_t> score(greedy ? (size_t)N : 0, 0), touched;
+  std::vector<uint8_t> done(greedy ? (size_t)N : 0, 0);
+  size_t next_in_order = 0;
+  auto reset_candidates = [&]() {
+    for (const int32_t u : touched) score[u] = 0;
+    touched.clear();
+    heap.clear();
+  };
+  auto next_vertex = [&]() -> int32_t {
+    if (greedy) {
+      while (!heap.empty()) {
+        std::pop_heap(heap.begin(), heap.end());
+        const Cand c = heap.back();
+        heap.pop_back();
+        if (!done[c.v] && score[c.v] == c.shared) return c.v;  // else: stale entry
+      }
+      while (next_in_order < order.size() && done[order[next_in_order]]) next_in_order++;
+    }
+    return next_in_order < order.size() ? order[next_in_order++] : -1;
+  };
   open_panel();
-  for (const int32_t v : order) {
+  for (int32_t v = next_vertex(); v >= 0; v = next_vertex()) {
     int32_t pid = (int32_t)f.panels.size();
     int32_t new_slots = 0, new_mem = 0;
     for (int32_t p = ptr_v[v]; p < ptr_v[v + 1]; p++) {
@@ -150,7 +185,9 @@ void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_
       close_panel();
       open_panel();
       pid = (int32_t)f.panels.size();
+      if (greedy) reset_candidates();
     }
+    if (greedy) done[v] = 1;
     for (int32_t p = ptr_v[v]; p < ptr_v[v + 1]; p++) {
       const int32_t e = ind_v[p];
       if (stamp[e] != pid) {
@@ -162,6 +199,14 @@ void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_
         } else {
           f.pmem.insert(f.pmem.end(), ind_t + ptr_t[e], ind_t + ptr_t[e + 1]);
           f.slot_eid.push_back(e);
+          if (greedy)
+            for (int32_t q = ptr_t[e]; q < ptr_t[e + 1]; q++) {
+              const int32_t u = ind_t[q];
+              if (done[u] || is_hub[u]) continue;
+              if (score[u]++ == 0) touched.push_back(u);
+              heap.push_back(Cand{(float)score[u] / (float)(ptr_v[u + 1] - ptr_v[u]), score[u], u});
+              std::push_heap(heap.begin(), heap.end());
+            }
         }
         f.soff.push_back((int32_t)f.pmem.size() - cur.pm0);
       }

@@ -25,8 +25,10 @@ def _stream_handle(device):
 
 
 def make_opts(short_max=0, split_len=0, panel_rows=0, panel_nnz=0, xcd_remap=True, host_only=False,
-              t_big=0, fused_tile_bytes=0):
+              t_big=0, fused_tile_bytes=0, dfs_order=False):
     flags = 0
+    if dfs_order:
+        flags |= _lib.HG_PLAN_DFS_ORDER
     if host_only:
         flags |= _lib.HG_PLAN_HOST_ONLY
     if not xcd_remap:

@@ -79,6 +79,7 @@ typedef struct hg_plan_opts {
 
 #define HG_PLAN_HOST_ONLY 1 /* build the schedule on the host, upload nothing (tests) */
 #define HG_PLAN_NO_XCD_REMAP 2 /* keep blockIdx -> panel identity mapping */
+#define HG_PLAN_DFS_ORDER 4 /* fused: panel rows in plain depth-first order (no greedy growth) */
 
 typedef struct hg_plan_info {
   int32_t N, M;
