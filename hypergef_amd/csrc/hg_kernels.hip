@@ -314,9 +314,10 @@ __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
 
   float *tile = reinterpret_cast<float *>(smem);        // [cap * TW]
   int32_t *rec = smem + a.cap * TW;                      // [max_rec_words], 16-byte aligned
+  // scale staging exists only for the scales this call has (the launcher sizes LDS the same way)
   float *sA = reinterpret_cast<float *>(rec + a.max_rec_words);  // [cap]
   float *sB = sA + a.cap;                                // [cap]
-  float *sdeg = sB + a.cap;                              // [rows_cap]
+  float *sdeg = (a.degE || a.W) ? sB + a.cap : sA;       // [rows_cap]
 
   // records are padded to whole 16-byte units: one dwordx4 per lane copies 4 KB per pass
   for (int i = tid; i < (rt.len >> 2); i += BS)
@@ -568,8 +569,10 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
   FusedArgs ad = a;
   ad.debug = t.fused_debug;
   const dim3 grid(a.npanels, col_tiles);
+  // tile | record | scale staging (only what this call's scales need: without them the F = 32
+  // bench shape fits 8 workgroups per CU instead of 7)
   const size_t lds_p = (size_t)a.cap * TW * 4 + (size_t)a.max_rec_words * 4 +
-                       (size_t)(2 * a.cap + a.rows_cap) * 4 + 16;
+                       (size_t)(((a.degE || a.W) ? 2 * a.cap : 0) + (a.degV ? a.rows_cap : 0)) * 4 + 16;
   if constexpr (VEC == 4) {
     const bool fast = t.fused_fast && a.x_bytes > 0 && a.nrows_x < (1 << 24) && a.F < (1 << 22) &&
                       (!a.Xe_mat || a.mat_bytes > 0);
