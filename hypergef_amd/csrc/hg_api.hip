@@ -177,7 +177,7 @@ int get_fused(const hg_plan *cp, int32_t F, bool vec4, const hg::FusedSched **ou
 
 // workspace carve-up: [Xe: M*F][partials hop 0][partials hop 1]
 struct Carve {
-  size_t xe, part[2], ctr, total;
+  size_t xe, part[2], total;
 };
 Carve carve(const hg_plan *p, int32_t F) {
   Carve c;
@@ -187,8 +187,6 @@ Carve carve(const hg_plan *p, int32_t F) {
     c.part[h] = off;
     off += round256((size_t)p->sched[h].nslots * F * sizeof(float));
   }
-  c.ctr = off;  // 8 work counters, one per XCD class, 64 bytes apart
-  off += 512;
   c.total = off;
   return c;
 }
@@ -644,7 +642,6 @@ int hg_aggr_fused_f32(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
     a.eid_all = f->d_eid_all;
     a.max_rec_words = f->max_rec_words;
     a.ng = f->ng;
-    a.counters = reinterpret_cast<int32_t *>(ws + c.ctr);
     const int64_t xb = (int64_t)plan->N * F * 4, mb = (int64_t)f->n_mat * F * 4;
     a.x_bytes = xb < ((int64_t)1 << 31) ? (int32_t)xb : 0;
     a.mat_bytes = mb < ((int64_t)1 << 31) ? (int32_t)mb : 0;

@@ -39,7 +39,6 @@ struct FusedArgs {
   float *Y;
   int32_t F;
   int32_t xcd_remap;
-  int32_t *counters;      // 8 x 16 ints of per-XCD-class work counters (persistent kernel)
   int32_t x_bytes;        // byte size of X if it fits a buffer descriptor (< 2 GiB), else 0
   int32_t mat_bytes;      // same for the materialised table
   int32_t nrows_x;        // rows of X
