@@ -9,7 +9,8 @@ from . import _lib  # noqa: F401
 from . import ops, plan, synth  # noqa: F401
 from .balancer import balance_schedule  # noqa: F401
 from .hypergraph import HyperGraph  # noqa: F401
-from .ops import HGNNAggr, UniGNNConv, UniGNNConvdeg  # noqa: F401
+from .ops import (HGNNAggr, HGNNAggrLinear, UniGNNConv, UniGNNConvdeg, UniGNNConvLinear,  # noqa: F401
+                  hgnnaggr_linear)
 from .plan import Plan  # noqa: F401
 
 # The reference builds two top-level extension modules (setup.py:18,32-33).

@@ -579,10 +579,21 @@ int hg_scatter_record_f32(int32_t N, int32_t M, int32_t F, const float *T, const
   return HG_OK;
 }
 
-int hg_aggr_fused_f32(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
-                      const int32_t *colind_t, const float *X, const float *degE,
-                      const float *degV, const float *W, float *Y, void *workspace,
-                      size_t workspace_bytes, int32_t variant, hg_stream_t stream) {
+// Shared body of hg_aggr_fused_f32 and hg_aggr_linear_f32.  With lin != nullptr the caller
+// wants (aggregated rows) * Wlin^T in lin->Y: the fused panels do that in their epilogue when
+// they can (lin->done = true); otherwise the aggregated rows go to Y as usual and the caller
+// runs the standalone linear kernel over them.
+struct LinReq {
+  const float *Wlin;
+  int32_t F_out;
+  float *Y;
+  bool done;
+};
+
+static int aggr_impl(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
+                     const int32_t *colind_t, const float *X, const float *degE,
+                     const float *degV, const float *W, float *Y, void *workspace,
+                     size_t workspace_bytes, int32_t variant, hg_stream_t stream, LinReq *lin) {
   if (variant == HG_VARIANT_PUSH_ATOMIC) {
     if (!plan) {
       hg::set_error("null plan");
@@ -651,6 +662,16 @@ int hg_aggr_fused_f32(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
     a.bsA = bound ? f->d_bsA : nullptr;
     a.bsB = bound ? f->d_bsB : nullptr;
     a.bsD = bound ? f->d_bsD : nullptr;
+    if (lin && f->n_hub == 0 && vec4) {  // hub rows are produced outside the panels: no epilogue then
+      a.Wlin = lin->Wlin;
+      a.F_out = lin->F_out;
+      if (hg::fused_linear_ok(a)) {
+        a.Y = lin->Y;
+        lin->done = true;
+      } else {
+        a.Wlin = nullptr;
+      }
+    }
     hipError_t e = hg::launch_fused(a, vec4, s);
     if (e != hipSuccess) return hip_fail("fused_panel launch", e);
     return HG_OK;
@@ -662,6 +683,98 @@ int hg_aggr_fused_f32(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
   // hop 2: Y[v] = (sum_{e contains v} Xe[e]) * degV[v]
   return run_hop(plan, 1, F, plan->d_ptr_v, plan->d_ind_v, Xe, degV, nullptr, Y,
                  reinterpret_cast<float *>(ws + c.part[1]), s);
+}
+
+int hg_aggr_fused_f32(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
+                      const int32_t *colind_t, const float *X, const float *degE,
+                      const float *degV, const float *W, float *Y, void *workspace,
+                      size_t workspace_bytes, int32_t variant, hg_stream_t stream) {
+  return aggr_impl(plan, F, csrptr_t, colind_t, X, degE, degV, W, Y, workspace, workspace_bytes, variant,
+                   stream, nullptr);
+}
+
+int hg_linear_pack_f32(int32_t F_out, int32_t F_in, const float *Wlin, float *wfrag, hg_stream_t stream) {
+  if (!Wlin || !wfrag || F_out <= 0 || (F_out % 16) || (F_in != 32 && F_in != 64 && F_in != 128)) {
+    hg::set_error("hg_linear_pack_f32: need F_in in {32, 64, 128}, F_out a positive multiple of 16");
+    return Wlin && wfrag ? HG_ERR_UNSUPPORTED : HG_ERR_INVALID;
+  }
+  hipError_t e = hg::launch_linear_pack(F_out, F_in, Wlin, wfrag, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return hip_fail("linear_pack launch", e);
+  return HG_OK;
+}
+
+int hg_linear_rows_f32(int64_t nrows, int32_t F_in, int32_t F_out, const float *T, const float *wfrag, float *Y,
+                       hg_stream_t stream) {
+  if (nrows < 0 || !wfrag || (nrows > 0 && (!T || !Y))) {
+    hg::set_error("hg_linear_rows_f32: bad argument");
+    return HG_ERR_INVALID;
+  }
+  if (F_out <= 0 || (F_out % 16) || (F_in != 32 && F_in != 64 && F_in != 128)) {
+    hg::set_error("hg_linear_rows_f32: need F_in in {32, 64, 128}, F_out a positive multiple of 16");
+    return HG_ERR_UNSUPPORTED;
+  }
+  if (!aligned16(T) || !aligned16(wfrag) || !aligned16(Y)) {
+    hg::set_error("hg_linear_rows_f32: arrays must be 16-byte aligned");
+    return HG_ERR_INVALID;
+  }
+  hg::LinearArgs la;
+  la.T = T;
+  la.Wlin = wfrag;
+  la.rowmap = nullptr;
+  la.Y = Y;
+  la.nrows = nrows;
+  la.F_in = F_in;
+  la.F_out = F_out;
+  hipError_t e = hg::launch_linear(la, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return hip_fail("linear_rows launch", e);
+  return HG_OK;
+}
+
+size_t hg_aggr_linear_workspace_bytes(const hg_plan *plan, int32_t F_in) {
+  if (!plan || F_in <= 0) return 0;
+  return hg_plan_workspace_bytes(plan, F_in) + round256((size_t)plan->N * F_in * sizeof(float));
+}
+
+int hg_aggr_linear_f32(const hg_plan *plan, int32_t F_in, int32_t F_out, const int32_t *csrptr_t,
+                       const int32_t *colind_t, const float *X, const float *degE, const float *degV,
+                       const float *W, const float *wfrag, float *Y, void *workspace,
+                       size_t workspace_bytes, int32_t variant, hg_stream_t stream) {
+  if (!plan || !wfrag || !Y) {
+    hg::set_error("hg_aggr_linear_f32: null argument");
+    return HG_ERR_INVALID;
+  }
+  if (F_out <= 0 || (F_out % 16) || (F_in != 32 && F_in != 64 && F_in != 128)) {
+    hg::set_error("hg_aggr_linear_f32: need F_in in {32, 64, 128}, F_out a positive multiple of 16");
+    return HG_ERR_UNSUPPORTED;
+  }
+  if (variant == HG_VARIANT_PUSH_ATOMIC) {
+    hg::set_error("hg_aggr_linear_f32: push-atomic variant not supported");
+    return HG_ERR_UNSUPPORTED;
+  }
+  const size_t base = hg_plan_workspace_bytes(plan, F_in);
+  if (!workspace || workspace_bytes < hg_aggr_linear_workspace_bytes(plan, F_in)) {
+    hg::set_error("hg_aggr_linear_f32: workspace smaller than hg_aggr_linear_workspace_bytes");
+    return HG_ERR_WORKSPACE;
+  }
+  if (!aligned16(wfrag) || !aligned16(Y)) {
+    hg::set_error("hg_aggr_linear_f32: wfrag and Y must be 16-byte aligned");
+    return HG_ERR_INVALID;
+  }
+  float *T = reinterpret_cast<float *>(static_cast<char *>(workspace) + round256(base));
+  LinReq lin{wfrag, F_out, Y, false};
+  int rc = aggr_impl(plan, F_in, csrptr_t, colind_t, X, degE, degV, W, T, workspace, base, variant, stream, &lin);
+  if (rc != HG_OK || lin.done) return rc;
+  hg::LinearArgs la;
+  la.T = T;
+  la.Wlin = wfrag;
+  la.rowmap = nullptr;
+  la.Y = Y;
+  la.nrows = plan->N;
+  la.F_in = F_in;
+  la.F_out = F_out;
+  hipError_t e = hg::launch_linear(la, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return hip_fail("linear_rows launch", e);
+  return HG_OK;
 }
 
 }  // extern "C"

@@ -43,6 +43,19 @@ struct FusedArgs {
   int32_t mat_bytes;      // same for the materialised table
   int32_t nrows_x;        // rows of X
   int32_t debug = 0;      // ablation / stamp bits (experiments only)
+  // fused linear epilogue (hg_aggr_linear_f32): Y[N, F_out] = (aggregated rows) * Wlin^T
+  const float *Wlin = nullptr;  // Wlin [F_out, F] in MFMA fragment order (launch_linear_pack), or null
+  int32_t F_out = 0;
+};
+
+// Y[rowmap ? rowmap[r] : r, :] = T[r, :] * Wlin^T for r < nrows; T is [nrows, F_in] row-major.
+struct LinearArgs {
+  const float *T;
+  const float *Wlin;  // [F_out, F_in] in MFMA fragment order (launch_linear_pack)
+  const int32_t *rowmap;
+  float *Y;
+  int64_t nrows;
+  int32_t F_in, F_out;
 };
 
 struct PushArgs {
@@ -57,6 +70,9 @@ struct PushArgs {
 hipError_t launch_gather(const GatherArgs &a, int nfix, int nfix_l1, const Fixup *fixups, bool vec4,
                          hipStream_t stream);
 hipError_t launch_fused(const FusedArgs &a, bool vec4, hipStream_t stream);
+bool fused_linear_ok(const FusedArgs &a);  // can launch_fused run this call's linear epilogue?
+hipError_t launch_linear(const LinearArgs &a, hipStream_t stream);
+hipError_t launch_linear_pack(int32_t F_out, int32_t F_in, const float *Wlin, float *wfrag, hipStream_t stream);
 int fused_tile_row_floats(int F, bool vec4);
 hipError_t read_stamps(unsigned long long *out, bool reset);
 hipError_t launch_push(const PushArgs &a, hipStream_t stream);

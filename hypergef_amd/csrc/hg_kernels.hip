@@ -267,6 +267,233 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// ---- fp32 MFMA: rows of an LDS tile times Wlin^T ------------------------------------
+// The one dense contraction next to the path (the nn.Linear of HGNNConv / UniGIN, reference
+// model/ugsys/hgnn.py:22).  v_mfma_f32_16x16x4_f32: exact f32 (a k-ordered fmaf chain), A and
+// B one VGPR per lane -- lane l holds A[row l&15][k l>>4] and B[k l>>4][col l&15], D is
+// row 4*(l>>4)+i, col l&15 in register i.
+// A wave owns 16-column tiles of the output: the K/4 B fragments of a tile (= 16 rows of
+// Wlin) sit in K/4 VGPRs, read straight from global memory (L2-resident, 4 KB per tile), and
+// are reused for every row of the panel, so Wlin takes no LDS and no barrier.  The A
+// fragments come from the panel's rows in LDS (row stride K+4 floats: the 64 lanes of a read
+// fall on every bank exactly twice), up to four 16-row tiles at a time = four independent
+// accumulators, which is what the 40-cycle dependent latency of the instruction needs.
+typedef float hg_f4 __attribute__((ext_vector_type(4)));
+
+struct LinSplit {  // how the four waves share (column tile, row tile) space
+  int nt_first, nt_step, rt_first, rt_step;
+  bool active;
+};
+__device__ __forceinline__ LinSplit lin_split(int wid, int NT) {
+  const int nwn = NT >= 4 ? 4 : (NT == 3 ? 3 : NT);  // waves across column tiles
+  const int nwr = NT >= 3 ? 1 : 4 / nwn;             // waves across row tiles
+  LinSplit s;
+  s.nt_first = wid % nwn;
+  s.nt_step = nwn;
+  s.rt_first = wid / nwn;
+  s.rt_step = nwr;
+  s.active = wid < nwn * nwr;
+  return s;
+}
+
+// Wlin arrives packed in fragment order (linear_pack_kernel): the K/4 B fragments of a column
+// tile are K/16 coalesced dwordx4 reads per lane (two 128-byte lines per 4 fragments).  Read
+// straight from the row-major matrix the same fragments touch 16 lines per instruction -- more
+// line requests per panel than the whole X gather.
+//   wfrag[((nt * K/16 + q) * 64 + lane) * 4 + j] = Wlin[nt*16 + (lane & 15)][(4q + j)*4 + (lane >> 4)]
+template <int KSTEPS>
+__device__ __forceinline__ void load_bfrag(const float *wfrag, int nt, int lane, float (&bv)[KSTEPS]) {
+  const float4 *w = reinterpret_cast<const float4 *>(wfrag) + (int64_t)nt * (KSTEPS / 4) * 64 + lane;
+#pragma unroll
+  for (int q = 0; q < KSTEPS / 4; q++) {
+    const float4 f = w[q * 64];
+    bv[q * 4 + 0] = f.x;
+    bv[q * 4 + 1] = f.y;
+    bv[q * 4 + 2] = f.z;
+    bv[q * 4 + 3] = f.w;
+  }
+}
+
+__global__ __launch_bounds__(256) void linear_pack_kernel(int32_t F_out, int32_t F_in, const float *Wlin,
+                                                          float *wfrag) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)F_out * F_in) return;
+  const int j = (int)(i & 3), lane = (int)((i >> 2) & 63);
+  const int64_t u = i >> 8;  // nt * K/16 + q
+  const int k16 = F_in >> 4;
+  const int q = (int)(u % k16), nt = (int)(u / k16);
+  wfrag[i] = Wlin[(int64_t)(nt * 16 + (lane & 15)) * F_in + (4 * q + j) * 4 + (lane >> 4)];
+}
+
+// NRT row tiles rt0, rt0 + rt_step, ... against one column tile whose B fragments are in bv.
+template <int KSTEPS, int NRT>
+__device__ __forceinline__ void mfma_rows(const float *t, int ld, int rt0, int rt_step, const float (&bv)[KSTEPS],
+                                          hg_f4 *acc, int lane) {
+  const float *ta = t + (rt0 * 16 + (lane & 15)) * ld + (lane >> 4);
+  const int tstep = rt_step * 16 * ld;
+#pragma unroll
+  for (int j = 0; j < NRT; j++) acc[j] = hg_f4{0.f, 0.f, 0.f, 0.f};
+  // A fragments two steps ahead of the MFMAs that use them (an LDS read takes about as long as
+  // the NRT MFMAs of one step).  The scheduling barriers pin that order: left alone the compiler
+  // either hoists all K/4 * NRT reads to the top (3 waves/SIMD) or sinks them next to their use.
+  float a0[NRT], a1[NRT], a2[NRT];
+#pragma unroll
+  for (int j = 0; j < NRT; j++) a0[j] = ta[j * tstep];
+  if (KSTEPS > 1) {
+#pragma unroll
+    for (int j = 0; j < NRT; j++) a1[j] = ta[j * tstep + 4];
+  }
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ks++) {
+    if (ks + 2 < KSTEPS) {
+#pragma unroll
+      for (int j = 0; j < NRT; j++) a2[j] = ta[j * tstep + (ks + 2) * 4];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NRT; j++)
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], bv[ks], acc[j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NRT; j++) {
+      a0[j] = a1[j];
+      a1[j] = a2[j];
+    }
+  }
+}
+
+template <int KSTEPS>
+__device__ __forceinline__ void mfma_rows_n(int n, const float *t, int ld, int rt0, int rt_step,
+                                            const float (&bv)[KSTEPS], hg_f4 *acc, int lane) {
+  switch (n) {  // wave-uniform
+    case 4: mfma_rows<KSTEPS, 4>(t, ld, rt0, rt_step, bv, acc, lane); break;
+    case 3: mfma_rows<KSTEPS, 3>(t, ld, rt0, rt_step, bv, acc, lane); break;
+    case 2: mfma_rows<KSTEPS, 2>(t, ld, rt0, rt_step, bv, acc, lane); break;
+    case 1: mfma_rows<KSTEPS, 1>(t, ld, rt0, rt_step, bv, acc, lane); break;
+    default: break;
+  }
+}
+
+// The rows t[0 .. nrows) (LDS, stride K+4) times Wlin^T -> Y.  Called by all 256 threads once the
+// rows are complete.  bv: the B fragments of the wave's first column tile, which the caller
+// loaded ahead of time to hide their latency.
+// F_out <= K: the results go back into `t` (two barriers) and leave as whole rows, 16 bytes per
+// lane -- a row written as four 64-byte pieces by four waves at four different times costs the
+// memory system partial-line writes.  NPW = column tiles per wave (1 or 2).
+template <int KSTEPS, int NPW>
+__device__ __forceinline__ void panel_times_wt_staged(float *t, int nrows, int F_out, const float *Wlin,
+                                                      const int32_t *rowmap, int64_t row0, float *Y, int tid,
+                                                      float (&bv)[KSTEPS]) {
+  constexpr int K = KSTEPS * 4, LD = K + 4, RPN = 4 / NPW;  // row tiles per column tile and wave
+  const int lane = tid & 63;
+  const int NT = F_out >> 4, RT = (nrows + 15) >> 4;
+  const LinSplit sp = lin_split(tid >> 6, NT);
+  hg_f4 acc[4];
+  int nrt = 0;
+  if (sp.active) {
+    nrt = min(RPN, max(0, (RT - sp.rt_first + sp.rt_step - 1) / sp.rt_step));
+#pragma unroll
+    for (int ni = 0; ni < NPW; ni++) {
+      const int nt = sp.nt_first + ni * sp.nt_step;
+      if (nt < NT) {
+        if (ni > 0) load_bfrag<KSTEPS>(Wlin, nt, lane, bv);
+        mfma_rows_n<KSTEPS>(nrt, t, LD, sp.rt_first, sp.rt_step, bv, acc + ni * RPN, lane);
+      }
+    }
+  }
+  __syncthreads();  // every wave has read its A fragments: the rows can be overwritten
+  if (sp.active) {
+#pragma unroll
+    for (int ni = 0; ni < NPW; ni++) {
+      const int nt = sp.nt_first + ni * sp.nt_step;
+      if (nt < NT) {
+#pragma unroll
+        for (int j = 0; j < RPN; j++)
+          if (j < nrt) {
+            float *d = t + ((sp.rt_first + j * sp.rt_step) * 16 + 4 * (lane >> 4)) * LD + nt * 16 + (lane & 15);
+#pragma unroll
+            for (int i = 0; i < 4; i++) d[i * LD] = acc[ni * RPN + j][i];
+          }
+      }
+    }
+  }
+  __syncthreads();
+  const int q = F_out >> 2;  // float4 pieces per row
+  for (int i = tid; i < nrows * q; i += 256) {
+    const int r = i / q, c = (i - r * q) * 4;
+    const int64_t yrow = rowmap ? (int64_t)rowmap[r] : row0 + r;
+    *reinterpret_cast<float4 *>(Y + yrow * F_out + c) = *reinterpret_cast<const float4 *>(t + r * LD + c);
+  }
+}
+
+template <int KSTEPS>
+__device__ __forceinline__ void panel_times_wt(float *t, int nrows, int F_out, const float *Wlin,
+                                               const int32_t *rowmap, int64_t row0, float *Y, int tid,
+                                               float (&bv)[KSTEPS]) {
+  constexpr int K = KSTEPS * 4, LD = K + 4;
+  const int nt_all = F_out >> 4, nwr = nt_all >= 3 ? 1 : 4 / nt_all;  // as lin_split
+  const int rt_per_wave = (((nrows + 15) >> 4) + nwr - 1) / nwr;
+  if (F_out <= K && rt_per_wave <= (F_out > 64 ? 2 : 4)) {  // workgroup-uniform
+    if (F_out > 64) panel_times_wt_staged<KSTEPS, 2>(t, nrows, F_out, Wlin, rowmap, row0, Y, tid, bv);
+    else panel_times_wt_staged<KSTEPS, 1>(t, nrows, F_out, Wlin, rowmap, row0, Y, tid, bv);
+    return;
+  }
+  // wider output than input: results go straight to Y, 64 bytes per row and instruction
+  const int lane = tid & 63;
+  const int NT = F_out >> 4, RT = (nrows + 15) >> 4;
+  const LinSplit sp = lin_split(tid >> 6, NT);
+  if (!sp.active) return;
+  for (int nt = sp.nt_first; nt < NT; nt += sp.nt_step) {
+    if (nt != sp.nt_first) load_bfrag<KSTEPS>(Wlin, nt, lane, bv);
+    float *ycol = Y + nt * 16 + (lane & 15);
+    for (int rt = sp.rt_first; rt < RT; rt += 4 * sp.rt_step) {
+      const int n = min(4, (RT - rt + sp.rt_step - 1) / sp.rt_step);  // wave-uniform
+      hg_f4 acc[4];
+      mfma_rows_n<KSTEPS>(n, t, LD, rt, sp.rt_step, bv, acc, lane);
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (j < n) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const int r = (rt + j * sp.rt_step) * 16 + 4 * (lane >> 4) + i;
+            if (r < nrows) ycol[(rowmap ? (int64_t)rowmap[r] : row0 + r) * F_out] = acc[j][i];
+          }
+        }
+    }
+  }
+}
+
+// Standalone form: 64 (K = 128: 32) rows of T per workgroup through LDS.  Used where the
+// aggregation did not run the fused panels (pull variant, hub vertices).
+template <int KSTEPS> struct LinearRows {
+  static constexpr int R = KSTEPS >= 32 ? 32 : 64;
+};
+template <int KSTEPS>
+__global__ __launch_bounds__(256) void linear_rows_kernel(const LinearArgs a) {
+  constexpr int K = KSTEPS * 4, LD = K + 4, R = LinearRows<KSTEPS>::R;
+  __shared__ float t[R * LD];
+  const int64_t row0 = (int64_t)blockIdx.x * R;
+  const int nrows = (int)min((int64_t)R, a.nrows - row0);
+  float bv[KSTEPS];
+  const LinSplit sp = lin_split(threadIdx.x >> 6, a.F_out >> 4);
+  if (sp.active) load_bfrag<KSTEPS>(a.Wlin, sp.nt_first, threadIdx.x & 63, bv);
+  constexpr int NL = R * (K / 4) / 256;  // float4 loads per thread, all in flight before the first LDS write
+  float4 v[NL];
+#pragma unroll
+  for (int j = 0; j < NL; j++) {
+    const int i = threadIdx.x + j * 256, r = i / (K / 4), c = (i % (K / 4)) * 4;
+    v[j] = r < nrows ? *reinterpret_cast<const float4 *>(a.T + (row0 + r) * K + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int j = 0; j < NL; j++) {
+    const int i = threadIdx.x + j * 256, r = i / (K / 4), c = (i % (K / 4)) * 4;
+    *reinterpret_cast<float4 *>(t + r * LD + c) = v[j];
+  }
+  __syncthreads();
+  panel_times_wt<KSTEPS>(t, nrows, a.F_out, a.Wlin, a.rowmap ? a.rowmap + row0 : nullptr, row0, a.Y,
+                         threadIdx.x, bv);
+}
+
 // Packed form of the fused panel kernel.  The plan hands every panel over as ONE
 // contiguous int32 record (hg_fused.cpp, pack_records): a single coalesced copy
 // stages it, and hop 1 is a wave-uniform loop over a [step][group] entry stream in
@@ -288,7 +515,9 @@ typedef int hg_i4 __attribute__((ext_vector_type(4)));
 // MAT / SCALED say whether materialised slots / degE-W scaling can occur at all (the launcher
 // knows); false compiles that path out of the unrolled loop, which is issue-bound.  DBG keeps
 // the ablation switches (a.debug) in the code; production instances have none.
-template <int LPR, int VEC, int U, bool FAST, bool MAT, bool SCALED, bool DBG>
+// LIN: the rows a panel produces go through panel_times_wt (Y = rows * Wlin^T, F_out columns)
+// instead of straight to Y; needs F == LPR * VEC and at most 4 rows per lane group.
+template <int LPR, int VEC, int U, bool FAST, bool MAT, bool SCALED, bool DBG, bool LIN = false>
 __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
   constexpr int BS = 256;
   constexpr int NG = BS / LPR;
@@ -312,8 +541,8 @@ __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
   HG_STAMP(0);
   const int32_t *grec = a.rec + rt.off;
 
-  float *tile = reinterpret_cast<float *>(smem);        // [cap * TW]
-  int32_t *rec = smem + a.cap * TW;                      // [max_rec_words], 16-byte aligned
+  float *tile = reinterpret_cast<float *>(smem);        // [cap * TW]  (LIN: [cap * (TW + 4)])
+  int32_t *rec = smem + a.cap * (LIN ? TW + 4 : TW);     // [max_rec_words], 16-byte aligned
   // scale staging exists only for the scales this call has (the launcher sizes LDS the same way)
   float *sA = reinterpret_cast<float *>(rec + a.max_rec_words);  // [cap]
   float *sB = sA + a.cap;                                // [cap]
@@ -421,7 +650,40 @@ __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
   HG_STAMP(3);
   __syncthreads();
   HG_STAMP(4);
-  if (!(DBG && (a.debug & 8))) {  // ---- hop 2
+  if constexpr (LIN) {  // ---- hop 2 into registers, then rows * Wlin^T on the matrix cores
+    // the B fragments of this wave's first column tile: issued now, used after hop 2
+    float bv[TW / 4];
+    const LinSplit sp = lin_split(tid >> 6, a.F_out >> 4);
+    if (sp.active && !(a.debug & 512)) load_bfrag<TW / 4>(a.Wlin, sp.nt_first, tid & 63, bv);
+    const int rpg = (nrows + NG - 1) / NG;  // <= 4 (launcher)
+    const int r0 = min(g * rpg, nrows), r1 = min(r0 + rpg, nrows);
+    V outr[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      outr[i] = V::zero();
+      const int r = r0 + i;
+      if (r < r1) {
+        const int pb = r ? pend[r - 1] : 0, pe = pend[r];
+        for (int p = pb; p < pe; p++) outr[i].add(V::load(tile + (int)pvs[p] * TW + lcol));
+        if (a.degV && pe > pb) outr[i].mul(sdeg[r]);
+      }
+    }
+    __syncthreads();  // every slot row has been read: the tile becomes the [rows][TW + 4] operand
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      if (r0 + i < r1) outr[i].store(tile + (r0 + i) * (TW + 4) + lcol);
+    __syncthreads();
+    if (a.debug & 256) {  // ablation (timing only): no matrix work, the rows leave as they are
+      const int q = min(a.F_out, TW) >> 2;
+      for (int i = tid; i < nrows * q; i += 256) {
+        const int r = i / q, c = (i - r * q) * 4;
+        *reinterpret_cast<float4 *>(a.Y + (int64_t)prow[r] * a.F_out + c) =
+            *reinterpret_cast<const float4 *>(tile + r * (TW + 4) + c);
+      }
+      return;
+    }
+    panel_times_wt<TW / 4>(tile, nrows, a.F_out, a.Wlin, prow, 0, a.Y, tid, bv);
+  } else if (!(DBG && (a.debug & 8))) {  // ---- hop 2
     const int rpg = (nrows + NG - 1) / NG;
     const int r0 = min(g * rpg, nrows), r1 = min(r0 + rpg, nrows);
     for (int r = r0; r < r1; r++) {
@@ -576,6 +838,25 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
   if constexpr (VEC == 4) {
     const bool fast = t.fused_fast && a.x_bytes > 0 && a.nrows_x < (1 << 24) && a.F < (1 << 22) &&
                       (!a.Xe_mat || a.mat_bytes > 0);
+    if (a.Wlin) {  // linear epilogue: eligibility was checked by fused_linear_ok
+      if constexpr (TW == 32 || TW == 64 || TW == 128) {
+        if (!fast || a.F != TW || a.rows_cap > 4 * (256 / LPR) || (a.F_out & 15)) return hipErrorInvalidValue;
+        const size_t lds_l = lds_p + (size_t)a.cap * 4 * 4;  // + 4 pad floats per tile row
+        const int spec = (a.Xe_mat ? 1 : 0) | ((a.degE || a.W) ? 2 : 0);
+#define HG_PKL(M, S) \
+  hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 8, true, M, S, false, true>), grid, dim3(256), lds_l, stream, ad)
+        switch (spec) {
+          case 0: HG_PKL(false, false); break;
+          case 1: HG_PKL(true, false); break;
+          case 2: HG_PKL(false, true); break;
+          default: HG_PKL(true, true); break;
+        }
+#undef HG_PKL
+        return hipGetLastError();
+      } else {
+        return hipErrorInvalidValue;
+      }
+    }
     if (fast) {
       if (t.fused_debug) {  // ablation / stamp run: everything kept at run time
         hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 8, true, true, true, true>), grid, dim3(256), lds_p, stream, ad);
@@ -606,9 +887,43 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
       return hipGetLastError();
     }
   }
+  if (a.Wlin) return hipErrorInvalidValue;
   hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 8, false, true, true, true>), grid, dim3(256), lds_p, stream, ad);
   return hipGetLastError();
 }
+
+hipError_t launch_linear_pack(int32_t F_out, int32_t F_in, const float *Wlin, float *wfrag, hipStream_t stream) {
+  if (F_out <= 0 || F_in <= 0 || (F_out & 15) || (F_in & 15)) return hipErrorInvalidValue;
+  const int64_t n = (int64_t)F_out * F_in;
+  hipLaunchKernelGGL(linear_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, F_out, F_in,
+                     Wlin, wfrag);
+  return hipGetLastError();
+}
+
+bool fused_linear_ok(const FusedArgs &a) {
+  const Tuning &t = tuning();
+  const int lpr = a.F / 4;
+  return (a.F == 32 || a.F == 64 || a.F == 128) && a.F_out > 0 && (a.F_out & 15) == 0 && t.fused_fast &&
+         !(t.fused_debug & 255) && a.x_bytes > 0 && a.nrows_x < (1 << 24) && (!a.Xe_mat || a.mat_bytes > 0) &&
+         a.ng == 256 / lpr && a.rows_cap <= 4 * (256 / lpr) && a.rows_cap == a.cap;
+}
+
+hipError_t launch_linear(const LinearArgs &a, hipStream_t stream) {
+  if (a.nrows == 0) return hipSuccess;
+  if ((a.F_out & 15) || a.F_out <= 0) return hipErrorInvalidValue;
+  const int R = a.F_in >= 128 ? 32 : 64;
+  const int64_t nb = (a.nrows + R - 1) / R;
+  if (nb > 0x7fffffffLL) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)nb), block(256);
+  switch (a.F_in) {
+    case 32: hipLaunchKernelGGL((linear_rows_kernel<8>), grid, block, 0, stream, a); break;
+    case 64: hipLaunchKernelGGL((linear_rows_kernel<16>), grid, block, 0, stream, a); break;
+    case 128: hipLaunchKernelGGL((linear_rows_kernel<32>), grid, block, 0, stream, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
 
 int fused_tile_row_floats(int F, bool vec4);
 

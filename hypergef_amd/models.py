@@ -17,7 +17,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .ops import HGNNAggr, UniGNNConv, UniGNNConvdeg
+from . import ops
+from .ops import HGNNAggr, HGNNAggrLinear, UniGNNConv, UniGNNConvdeg
 
 
 # ---- hgsys convolutions (model/ugsys/*.py) -----------------------------------
@@ -32,6 +33,9 @@ class HyperGsysHGNN(nn.Module):
         self.first_aggr = first_aggr
 
     def forward(self, X):
+        if ops._STATE["variant"] in ("auto", "pull", "fused"):
+            # same operator, one pass where that is faster (ops.set_fuse_linear; two-step otherwise)
+            return HGNNAggrLinear(self.hyperg, X, self.W.weight, self.degE, self.degV, self.Wdiag)
         X = self.W(X)
         return HGNNAggr(self.hyperg, X, self.degE, self.degV, self.Wdiag, self.first_aggr)
 

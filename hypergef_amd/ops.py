@@ -24,9 +24,10 @@ import ctypes
 import torch
 
 from . import _lib
-from .plan import Plan, cached_plan, _check_feat, _check_index, _ptr, _stream_handle
+from .plan import (Plan, cached_plan, linear_fusion_pays, linear_supported, _check_feat, _check_index, _ptr,
+                   _stream_handle)
 
-_STATE = {"variant": "auto", "backward": "reference"}
+_STATE = {"variant": "auto", "backward": "reference", "fuse_linear": "auto"}
 
 
 def set_variant(name):
@@ -41,6 +42,15 @@ def set_backward(mode):
     if mode not in ("reference", "adjoint"):
         raise ValueError("backward mode must be 'reference' or 'adjoint'")
     _STATE["backward"] = mode
+
+
+def set_fuse_linear(mode):
+    """hgnnaggr_linear / HGNNAggrLinear: 'auto' folds the projection into the aggregation where that
+    is faster (plan.linear_fusion_pays), 'always' wherever the kernel takes the widths, 'never' runs
+    linear-then-aggregate."""
+    if mode not in ("auto", "always", "never"):
+        raise ValueError("fuse_linear mode must be 'auto', 'always' or 'never'")
+    _STATE["fuse_linear"] = mode
 
 
 def _flat(t):
@@ -101,6 +111,70 @@ class _SumAggr(torch.autograd.Function):
         else:
             g = _forward(ctx.sched, csrptr_t, indices_t, grad_out * degV.reshape(-1, 1), degE, None, W)
         return (None,) * 6 + (g, None, None, None)
+
+
+class _SumAggrLinear(torch.autograd.Function):
+    """Aggr(X . Wlin^T) as one node: the layer's bias-free nn.Linear followed by the sum
+    aggregation (HyperGsysHGNN.forward, model/ugsys/hgnn.py:22-23; HyperGsysUinGINConv.forward,
+    unigin.py:20-21).  Forward runs hg_aggr_linear_f32 -- aggregate the F_in-wide rows, multiply
+    each finished row by Wlin^T on the matrix cores -- when the widths allow, else the two steps.
+    Backward is the two-step one: dZ = aggregation backward of grad_out (reference or adjoint
+    mode, as _SumAggr), dX = dZ . Wlin, dWlin = dZ^T . X."""
+
+    @staticmethod
+    def forward(ctx, csrptr_t, indices_t, node_feat, weight, degE, degV, W):
+        _check_feat(node_feat, "node_feat")
+        _check_feat(weight, "weight", device=node_feat.device)
+        _check_index(csrptr_t, "csrptr_t")
+        _check_index(indices_t, "indices_t")
+        if node_feat.dim() != 2 or weight.dim() != 2 or weight.shape[1] != node_feat.shape[1]:
+            raise ValueError("node_feat must be [N, F_in] and weight [F_out, F_in]")
+        degE, degV, W = _flat(degE), _flat(degV), _flat(W)
+        N, F_in = node_feat.shape
+        F_out = weight.shape[0]
+        variant = _STATE["variant"]
+        plan = cached_plan(N, csrptr_t, indices_t)
+        mode = _STATE["fuse_linear"]
+        fuse = (mode == "always" and linear_supported(F_in, F_out)) or \
+               (mode == "auto" and linear_fusion_pays(F_in, F_out))
+        if fuse and variant in ("auto", "pull", "fused"):
+            out = plan.aggregate_linear(csrptr_t, indices_t, node_feat, weight.detach().contiguous(),
+                                        degE, degV, W, variant=variant)
+        else:
+            out = _SumAggrLinear._aggr(csrptr_t, indices_t, torch.nn.functional.linear(node_feat, weight),
+                                       degE, degV, W)
+        ctx.graph = (csrptr_t, indices_t)
+        ctx.scales = (degE, degV, W)
+        ctx.save_for_backward(node_feat, weight)
+        return out
+
+    @staticmethod
+    def _aggr(csrptr_t, indices_t, feat, degE, degV, W):
+        # this operator has no group_* tensors: "push_groups" falls back to the plan's own schedule
+        variant = _STATE["variant"] if _STATE["variant"] != "push_groups" else "auto"
+        plan = cached_plan(feat.shape[0], csrptr_t, indices_t)
+        return plan.aggregate(csrptr_t, indices_t, feat.contiguous(), degE, degV, W, variant=variant)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        grad_out = grad_out.contiguous()
+        node_feat, weight = ctx.saved_tensors
+        degE, degV, W = ctx.scales
+        csrptr_t, indices_t = ctx.graph
+        if _STATE["backward"] == "reference" or degV is None:
+            dZ = _SumAggrLinear._aggr(csrptr_t, indices_t, grad_out, degE, degV, W)
+        else:
+            dZ = _SumAggrLinear._aggr(csrptr_t, indices_t, grad_out * degV.reshape(-1, 1), degE, None, W)
+        gx = dZ @ weight if ctx.needs_input_grad[2] else None
+        gw = dZ.t() @ node_feat if ctx.needs_input_grad[3] else None
+        return None, None, gx, gw, None, None, None
+
+
+def hgnnaggr_linear(csrptr_t, indices_t, node_feat, weight, degE=None, degV=None, W=None):
+    """Aggr(node_feat . weight^T) with the projection folded into the aggregation
+    (include/hg_aggr.h, hg_aggr_linear_f32).  degE / degV / W optional: all three = hgnnaggr,
+    degE + degV = unignnaggrdeg, none = unignnaggr."""
+    return _SumAggrLinear.apply(csrptr_t, indices_t, node_feat, weight, degE, degV, W)
 
 
 # ---- module `hgnnaggr` (hgnnaggr.cc:122-151) ---------------------------------
@@ -213,6 +287,16 @@ def HGNNAggr(hyperg, in_feat, degE, degV, Wdiag, first_aggr="sum"):
     it has a default so the reference test's 5-argument call works (hgnn_test.py:89)."""
     return hgnnaggr(hyperg.group_key, hyperg.group_row, hyperg.group_start, hyperg.group_end,
                     hyperg.H_T_csrptr, hyperg.H_T_colind, in_feat, degE, degV, Wdiag)
+
+
+def HGNNAggrLinear(hyperg, in_feat, weight, degE, degV, Wdiag):
+    """HGNNAggr(hyperg, in_feat . weight^T, ...) in one pass."""
+    return hgnnaggr_linear(hyperg.H_T_csrptr, hyperg.H_T_colind, in_feat, weight, degE, degV, Wdiag)
+
+
+def UniGNNConvLinear(dl, in_feat, weight):
+    """UniGNNConv(dl, in_feat . weight^T) in one pass."""
+    return hgnnaggr_linear(dl.H_T_csrptr, dl.H_T_colind, in_feat, weight)
 
 
 def UniGNNConvdeg(dl, in_feat, degE, degV):

@@ -149,6 +149,43 @@ class Plan:
                 _ptr(Y), _ptr(workspace), nbytes, _lib.VARIANTS[variant], _stream_handle(X.device)))
         return Y
 
+    def aggregate_linear(self, csrptr_t, colind_t, X, weight, degE=None, degV=None, W=None,
+                         variant="auto", out=None, workspace=None, packed=None):
+        """Y[N, F_out] = Aggr(X) . weight^T in one pass (hg_aggr_linear_f32); weight = nn.Linear.weight,
+        [F_out, F_in]; packed = pack_linear(weight) if the caller keeps it across calls.
+        Raises HgError(unsupported) for widths the MFMA epilogue does not take."""
+        _check_feat(X, "node_feat")
+        _check_feat(weight, "weight", device=X.device)
+        if X.shape[0] != self.N:
+            raise ValueError("node_feat has %d rows, hypergraph has %d vertices" % (X.shape[0], self.N))
+        F_in = X.shape[1]
+        if weight.dim() != 2 or weight.shape[1] != F_in:
+            raise ValueError("weight must be [F_out, F_in = %d]" % F_in)
+        F_out = weight.shape[0]
+        if packed is None:
+            packed = pack_linear(weight)
+        elif packed.numel() != weight.numel():
+            raise ValueError("packed does not belong to this weight")
+        weight = packed
+        for name, t, n in (("degE", degE, self.M), ("degV", degV, self.N), ("W", W, self.M)):
+            if t is not None:
+                _check_feat(t, name, device=X.device)
+                if t.numel() != n:
+                    raise ValueError("%s must have %d elements, got %d" % (name, n, t.numel()))
+        if (degE is not None or degV is not None or W is not None) and variant in ("auto", "fused"):
+            self._bind_scales(F_in, degE, degV, W, X.device)
+        Y = out if out is not None else torch.empty((self.N, F_out), dtype=torch.float32, device=X.device)
+        if workspace is None:
+            nbytes = int(_lib.lib().hg_aggr_linear_workspace_bytes(self._h, F_in))
+            workspace = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=X.device)
+        nbytes = workspace.numel() * workspace.element_size()
+        with torch.cuda.device(X.device):
+            _lib.check(_lib.lib().hg_aggr_linear_f32(
+                self._h, F_in, F_out, _ptr(csrptr_t), _ptr(colind_t), _ptr(X), _ptr(degE), _ptr(degV),
+                _ptr(W), _ptr(weight), _ptr(Y), _ptr(workspace), nbytes, _lib.VARIANTS[variant],
+                _stream_handle(X.device)))
+        return Y
+
     def _bind_scales(self, F, degE, degV, W, device):
         """Degree / weight vectors are graph constants: pre-gather them into the fused
         schedule's panel order once (hg_plan_bind_scales) and again only when a tensor is
@@ -179,6 +216,31 @@ class Plan:
                 self._h, hop, F, _ptr(csrptr_t), _ptr(colind_t), _ptr(src), _ptr(scaleA), _ptr(scaleB),
                 _ptr(dst), _ptr(workspace), nbytes, _stream_handle(src.device)))
         return dst
+
+
+def linear_supported(F_in, F_out):
+    """Widths hg_aggr_linear_f32 takes (MFMA tiles: K in {32, 64, 128}, 16-column output tiles)."""
+    return F_in in (32, 64, 128) and F_out > 0 and F_out % 16 == 0
+
+
+def linear_fusion_pays(F_in, F_out):
+    """Measured on MI355X (profiles/r01_linear_epilogue.md): folding the projection into the
+    aggregation wins 1.2-1.5x over linear-then-aggregate for F_in <= 64 when the projection does not
+    narrow the rows, ties at 128 -> 128 and loses when F_out < F_in (the aggregation then runs
+    at the wider F_in).  The operator layer fuses only where it wins."""
+    return linear_supported(F_in, F_out) and F_in <= 64 and F_out >= F_in
+
+
+def pack_linear(weight):
+    """nn.Linear.weight [F_out, F_in] -> the MFMA fragment order hg_aggr_linear_f32 reads
+    (hg_linear_pack_f32; one tiny kernel).  Re-pack after every weight update."""
+    _check_feat(weight, "weight")
+    F_out, F_in = weight.shape
+    wfrag = torch.empty(F_out * F_in, dtype=torch.float32, device=weight.device)
+    with torch.cuda.device(weight.device):
+        _lib.check(_lib.lib().hg_linear_pack_f32(F_out, F_in, _ptr(weight), _ptr(wfrag),
+                                                 _stream_handle(weight.device)))
+    return wfrag
 
 
 class _NullCtx:

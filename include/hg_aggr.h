@@ -205,6 +205,39 @@ HG_API int hg_aggr_fused_f32(const hg_plan *plan, int32_t F,
                       size_t workspace_bytes, int32_t variant,
                       hg_stream_t stream);
 
+/* Aggregation with the layer's dense projection folded in: the
+ * reference's HyperGsysHGNN / HyperGsysUinGINConv.forward run `X = self.W(X)` (nn.Linear
+ * without bias, model/ugsys/hgnn.py:22-23, unigin.py:20-21) and then the aggregation on
+ * the projected rows.  The aggregation is linear, so
+ *     Y[N, F_out] = Aggr(X * Wlin^T) = Aggr(X) * Wlin^T
+ * and this entry point aggregates the F_in-wide rows once and multiplies each finished
+ * row by Wlin^T on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32) before it is
+ * stored: X is read once and Y written once, the projected matrix never exists in HBM.
+ * Results equal the two-step form up to fp32 rounding order (both are fp32 fma chains).
+ *   Wlin   : [F_out, F_in] row-major device array (nn.Linear.weight)
+ *   wfrag  : F_out * F_in floats, 16-byte aligned: Wlin in MFMA fragment order.  Fill it with
+ *            hg_linear_pack_f32 after every weight update.  A wave keeps the fragments of
+ *            its output-column tile in registers; in this order they are K/16 coalesced
+ *            16-byte reads per lane (read from the row-major matrix they would touch more
+ *            cache lines per panel than the whole gather of X)
+ *   F_in in {32, 64, 128}; F_out a positive multiple of 16 (else HG_ERR_UNSUPPORTED and
+ *   the caller runs its own linear followed by hg_aggr_fused_f32)
+ * Where the fused panels cannot take the epilogue (pull variant, hub vertices) the
+ * aggregated rows go to the workspace and a standalone MFMA kernel projects them; the
+ * workspace is therefore hg_aggr_linear_workspace_bytes, not hg_plan_workspace_bytes. */
+HG_API int hg_linear_pack_f32(int32_t F_out, int32_t F_in, const float *Wlin, float *wfrag,
+                              hg_stream_t stream);
+HG_API size_t hg_aggr_linear_workspace_bytes(const hg_plan *plan, int32_t F_in);
+/* The projection alone, Y[nrows, F_out] = T[nrows, F_in] * Wlin^T, on the same MFMA kernel the
+ * fallback path of hg_aggr_linear_f32 uses (same width limits, same packed wfrag). */
+HG_API int hg_linear_rows_f32(int64_t nrows, int32_t F_in, int32_t F_out, const float *T,
+                              const float *wfrag, float *Y, hg_stream_t stream);
+HG_API int hg_aggr_linear_f32(const hg_plan *plan, int32_t F_in, int32_t F_out,
+                              const int32_t *csrptr_t, const int32_t *colind_t, const float *X,
+                              const float *degE, const float *degV, const float *W,
+                              const float *wfrag, float *Y, void *workspace, size_t workspace_bytes,
+                              int32_t variant, hg_stream_t stream);
+
 /* One hop only (CSR times dense with unit values, optional row scales):
  *   dst[r,:] = scaleB[r] * scaleA[r] * sum_{p in row r} src[ind[p],:]
  * hop = 0 walks H_T (nrows = M, src has N rows), hop = 1 walks the derived H

@@ -477,3 +477,87 @@ def test_bound_scales_follow_tensor_changes(hg, oracle):
     _lib.check(_lib.lib().hg_aggr_fused_f32(plan._h, F, _ptr(ptr), _ptr(ind), _ptr(x), _ptr(dE), _ptr(dV), _ptr(w3),
                                             _ptr(y3), _ptr(ws), ws.numel(), 3, _stream_handle(x.device)))
     assert torch.equal(y3, y_bound)
+
+
+# ---- aggregation with the layer's linear folded in (hg_aggr_linear_f32) ----------
+
+def _linear_ref(oracle, inc, X, Wlin, degE, degV, W, H_ptr, H_ind):
+    """The reference order: project (float64 product rounded once to fp32), then the oracle."""
+    Z = (X.astype(np.float64) @ Wlin.T.astype(np.float64)).astype(np.float32)
+    F_out = Wlin.shape[0]
+    if degE is None:
+        return oracle.hyperaggr_host(inc.N, F_out, H_ptr, H_ind, inc.csrptr, inc.colind, Z)
+    return oracle.hgnn_check(inc.N, inc.M, F_out, H_ptr, H_ind, inc.csrptr, inc.colind, Z, degE, degV, W)
+
+
+def _assert_close_linear(y, ref):
+    # (A X) W^T and A (X W^T) are the same fp32 fma chains in another order: relative to the
+    # size of the terms, not of a result that may have cancelled
+    y = y.detach().cpu().numpy()
+    scale = max(1.0, float(np.abs(ref).max()))
+    err = np.abs(y - ref)
+    assert err.max() <= 2e-5 * scale, "max err %g (scale %g)" % (err.max(), scale)
+    assert np.allclose(y, ref, rtol=1e-4, atol=2e-5 * scale)
+
+
+@pytest.mark.parametrize("shape", ["cora", "pubmed", "ragged", "powerlaw"])
+@pytest.mark.parametrize("F_in,F_out", [(32, 32), (64, 64), (64, 16), (128, 128), (32, 48), (128, 64)])
+def test_linear_epilogue_matches_two_step(hg, oracle, shape, F_in, F_out):
+    from hypergef_amd.plan import Plan
+    inc = _make(shape)
+    X, degE, degV, W, H_ptr, H_ind = _inputs(inc, F_in, oracle, seed=11, normal=True)
+    if shape == "powerlaw":
+        degE = np.where(np.isinf(degE), 0, degE).astype(np.float32)
+    rng = np.random.default_rng(12)
+    Wl = (rng.standard_normal((F_out, F_in)) / np.sqrt(F_in)).astype(np.float32)
+    ptr, ind = _dev(inc.csrptr), _dev(inc.colind)
+    plan = Plan.from_tensors(inc.N, ptr, ind)
+    wl = _dev(Wl)
+    ref_w = _linear_ref(oracle, inc, X, Wl, degE, degV, W, H_ptr, H_ind)
+    ref_u = _linear_ref(oracle, inc, X, Wl, None, None, None, H_ptr, H_ind)
+    for variant in ("auto", "pull", "fused"):
+        Yw = plan.aggregate_linear(ptr, ind, _dev(X), wl, _dev(degE.ravel()), _dev(degV.ravel()),
+                                   _dev(W), variant=variant)
+        _assert_close_linear(Yw, ref_w)
+        Yu = plan.aggregate_linear(ptr, ind, _dev(X), wl, variant=variant)
+        _assert_close_linear(Yu, ref_u)
+    # the epilogue is deterministic: same bits on a second call
+    Y2 = plan.aggregate_linear(ptr, ind, _dev(X), wl, variant="auto")
+    assert torch.equal(Y2, Yu if plan.auto_variant(F_in) == "fused" else Y2)
+
+
+def test_linear_unsupported_widths_and_autograd(hg, oracle):
+    from hypergef_amd import ops, _lib
+    from hypergef_amd.plan import Plan
+    inc = synth.cora_shape()
+    ptr, ind = _dev(inc.csrptr), _dev(inc.colind)
+    plan = Plan.from_tensors(inc.N, ptr, ind)
+    X = torch.randn(inc.N, 20, device=DEV)
+    with pytest.raises(_lib.HgError):  # K = 20 is not an MFMA width: the C ABI says unsupported
+        plan.aggregate_linear(ptr, ind, X, torch.zeros(16, 20, device=DEV))
+    hyperg = hg.HyperGraph.from_incidence(inc, DEV, ngs=1 << 30)
+    from hypergef_amd.plan import linear_fusion_pays
+    assert linear_fusion_pays(64, 64) and not linear_fusion_pays(64, 32) and not linear_fusion_pays(20, 16)
+    ops.set_fuse_linear("always")
+    try:
+        _linear_autograd_cases(hg, hyperg, inc, ((64, 32), (32, 64), (20, 7)))
+    finally:
+        ops.set_fuse_linear("auto")
+    _linear_autograd_cases(hg, hyperg, inc, ((64, 64), (64, 32)))  # fused where it pays / two-step
+
+
+def _linear_autograd_cases(hg, hyperg, inc, cases):
+    for F_in, F_out in cases:
+        torch.manual_seed(3)
+        X = torch.randn(inc.N, F_in, device=DEV, requires_grad=True)
+        Wl = (torch.randn(F_out, F_in, device=DEV) / F_in ** 0.5).requires_grad_()
+        Y = hg.HGNNAggrLinear(hyperg, X, Wl, hyperg.degE, hyperg.degV, torch.ones(inc.M, device=DEV))
+        G = torch.randn_like(Y)
+        gx, gw = torch.autograd.grad(Y, (X, Wl), G)
+        X2, W2 = X.detach().clone().requires_grad_(), Wl.detach().clone().requires_grad_()
+        Y_ref = hg.HGNNAggr(hyperg, torch.nn.functional.linear(X2, W2), hyperg.degE, hyperg.degV,
+                            torch.ones(inc.M, device=DEV))
+        gx_ref, gw_ref = torch.autograd.grad(Y_ref, (X2, W2), G)
+        assert torch.allclose(Y, Y_ref, rtol=1e-4, atol=1e-5)
+        assert torch.allclose(gx, gx_ref, rtol=1e-4, atol=1e-5)
+        assert torch.allclose(gw, gw_ref, rtol=1e-4, atol=1e-4)
