@@ -518,7 +518,7 @@ typedef int hg_i4 __attribute__((ext_vector_type(4)));
 // LIN: the rows a panel produces go through panel_times_wt (Y = rows * Wlin^T, F_out columns)
 // instead of straight to Y; needs F == LPR * VEC and at most 4 rows per lane group.
 template <int LPR, int VEC, int U, bool FAST, bool MAT, bool SCALED, bool DBG, bool LIN = false>
-__global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LIN ? (LPR >= 32 ? 5 : 8) : 1, 8))) void fused_packed_kernel(const FusedArgs a) {
   constexpr int BS = 256;
   constexpr int NG = BS / LPR;
   constexpr int TW = LPR * VEC;
@@ -651,10 +651,6 @@ __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
   __syncthreads();
   HG_STAMP(4);
   if constexpr (LIN) {  // ---- hop 2 into registers, then rows * Wlin^T on the matrix cores
-    // the B fragments of this wave's first column tile: issued now, used after hop 2
-    float bv[TW / 4];
-    const LinSplit sp = lin_split(tid >> 6, a.F_out >> 4);
-    if (sp.active && !(a.debug & 512)) load_bfrag<TW / 4>(a.Wlin, sp.nt_first, tid & 63, bv);
     const int rpg = (nrows + NG - 1) / NG;  // <= 4 (launcher)
     const int r0 = min(g * rpg, nrows), r1 = min(r0 + rpg, nrows);
     V outr[4];
@@ -668,6 +664,11 @@ __global__ __launch_bounds__(256) void fused_packed_kernel(const FusedArgs a) {
         if (a.degV && pe > pb) outr[i].mul(sdeg[r]);
       }
     }
+    // the B fragments of this wave's first column tile: in flight across the two barriers below
+    // (issued before hop 2 they would hold K/4 more registers through it: 78 instead of 64 VGPRs)
+    float bv[TW / 4];
+    const LinSplit sp = lin_split(tid >> 6, a.F_out >> 4);
+    if (sp.active && !(a.debug & 512)) load_bfrag<TW / 4>(a.Wlin, sp.nt_first, tid & 63, bv);
     __syncthreads();  // every slot row has been read: the tile becomes the [rows][TW + 4] operand
 #pragma unroll
     for (int i = 0; i < 4; i++)

@@ -225,10 +225,10 @@ def linear_supported(F_in, F_out):
 
 def linear_fusion_pays(F_in, F_out):
     """Measured on MI355X (profiles/r01_linear_epilogue.md): folding the projection into the
-    aggregation wins 1.2-1.5x over linear-then-aggregate for F_in <= 64 when the projection does not
-    narrow the rows, ties at 128 -> 128 and loses when F_out < F_in (the aggregation then runs
-    at the wider F_in).  The operator layer fuses only where it wins."""
-    return linear_supported(F_in, F_out) and F_in <= 64 and F_out >= F_in
+    aggregation beats linear-then-aggregate 1.5-1.8x at 32 -> 32 / 64 -> 64, still 1.1x at 64 -> 16
+    and 128 -> 128, and loses (0.86x) at 128 -> 64, where the aggregation would run at twice the
+    width it needs.  The operator layer fuses only where it wins."""
+    return linear_supported(F_in, F_out) and (F_in <= 64 or F_out >= F_in)
 
 
 def pack_linear(weight):

@@ -537,13 +537,14 @@ def test_linear_unsupported_widths_and_autograd(hg, oracle):
         plan.aggregate_linear(ptr, ind, X, torch.zeros(16, 20, device=DEV))
     hyperg = hg.HyperGraph.from_incidence(inc, DEV, ngs=1 << 30)
     from hypergef_amd.plan import linear_fusion_pays
-    assert linear_fusion_pays(64, 64) and not linear_fusion_pays(64, 32) and not linear_fusion_pays(20, 16)
+    assert linear_fusion_pays(64, 64) and linear_fusion_pays(64, 32) and not linear_fusion_pays(128, 64)
+    assert not linear_fusion_pays(20, 16)
     ops.set_fuse_linear("always")
     try:
         _linear_autograd_cases(hg, hyperg, inc, ((64, 32), (32, 64), (20, 7)))
     finally:
         ops.set_fuse_linear("auto")
-    _linear_autograd_cases(hg, hyperg, inc, ((64, 64), (64, 32)))  # fused where it pays / two-step
+    _linear_autograd_cases(hg, hyperg, inc, ((64, 64), (128, 64)))  # fused where it pays / two-step
 
 
 def _linear_autograd_cases(hg, hyperg, inc, cases):
