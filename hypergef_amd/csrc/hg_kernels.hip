@@ -469,7 +469,8 @@ template <int KSTEPS> struct LinearRows {
   static constexpr int R = KSTEPS >= 32 ? 32 : 64;
 };
 template <int KSTEPS>
-__global__ __launch_bounds__(256) void linear_rows_kernel(const LinearArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KSTEPS >= 32 ? 5 : 8, 8))) void linear_rows_kernel(
+    const LinearArgs a) {
   constexpr int K = KSTEPS * 4, LD = K + 4, R = LinearRows<KSTEPS>::R;
   __shared__ float t[R * LD];
   const int64_t row0 = (int64_t)blockIdx.x * R;

@@ -24,8 +24,8 @@ import ctypes
 import torch
 
 from . import _lib
-from .plan import (Plan, cached_plan, linear_fusion_pays, linear_supported, _check_feat, _check_index, _ptr,
-                   _stream_handle)
+from .plan import (Plan, cached_plan, linear_fusion_pays, linear_rows, linear_supported, _check_feat,
+                   _check_index, _ptr, _stream_handle)
 
 _STATE = {"variant": "auto", "backward": "reference", "fuse_linear": "auto"}
 
@@ -140,9 +140,11 @@ class _SumAggrLinear(torch.autograd.Function):
         if fuse and variant in ("auto", "pull", "fused"):
             out = plan.aggregate_linear(csrptr_t, indices_t, node_feat, weight.detach().contiguous(),
                                         degE, degV, W, variant=variant)
-        else:
-            out = _SumAggrLinear._aggr(csrptr_t, indices_t, torch.nn.functional.linear(node_feat, weight),
-                                       degE, degV, W)
+        else:  # project, then aggregate at F_out (own MFMA rows kernel where it takes the widths)
+            wd = weight.detach().contiguous()
+            Z = linear_rows(node_feat, wd) if linear_supported(F_in, F_out) and mode != "never" \
+                else torch.nn.functional.linear(node_feat, wd)
+            out = _SumAggrLinear._aggr(csrptr_t, indices_t, Z, degE, degV, W)
         ctx.graph = (csrptr_t, indices_t)
         ctx.scales = (degE, degV, W)
         ctx.save_for_backward(node_feat, weight)

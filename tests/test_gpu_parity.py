@@ -547,6 +547,16 @@ def test_linear_unsupported_widths_and_autograd(hg, oracle):
     _linear_autograd_cases(hg, hyperg, inc, ((64, 64), (128, 64)))  # fused where it pays / two-step
 
 
+def test_linear_rows_kernel(hg):
+    from hypergef_amd.plan import linear_rows
+    rng = np.random.default_rng(2)
+    for rows, F_in, F_out in ((1, 32, 16), (63, 64, 64), (200, 128, 48), (1000, 64, 144), (129, 128, 128)):
+        X = rng.standard_normal((rows, F_in)).astype(np.float32)
+        Wl = (rng.standard_normal((F_out, F_in)) / np.sqrt(F_in)).astype(np.float32)
+        ref = (X.astype(np.float64) @ Wl.T.astype(np.float64)).astype(np.float32)
+        _assert_close_linear(linear_rows(_dev(X), _dev(Wl)), ref)
+
+
 def _linear_autograd_cases(hg, hyperg, inc, cases):
     for F_in, F_out in cases:
         torch.manual_seed(3)
