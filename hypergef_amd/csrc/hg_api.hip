@@ -191,20 +191,23 @@ Carve carve(const hg_plan *p, int32_t F) {
   return c;
 }
 
-// What HG_VARIANT_AUTO resolves to.  Fused pays when most of the incidence mass sits
-// in hyperedges small enough to be recomputed per panel (measured, profiles/: cora /
-// citeseer / pubmed shapes 1.05-1.4x over the two-phase pull) and loses when nearly
-// everything has to be materialised anyway (power-law hubs).  First a free test on
-// the size histogram, then the built schedule.
+// What HG_VARIANT_AUTO resolves to.  Measured over the 13 dataset shapes, single graphs and
+// batches (profiles/r01_variant_choice.md): the fused panels win or tie wherever hub vertices
+// are few -- by 3x on small graphs, where one launch instead of two is what counts, and by
+// 0-35 % on large batches even when every hyperedge lands in four panels or 60 % of them are
+// materialised -- and lose only where hubs drag nearly every hyperedge into the materialised
+// table (yelp, the power-law config): the fused path is then the pull path plus overhead.
 int pick_variant(const hg_plan *plan, int32_t F, bool vec4, int32_t *variant,
                  const hg::FusedSched **f) {
   *variant = HG_VARIANT_PULL;
-  if (plan->small_nnz_frac >= 0.5) {
-    int rc = get_fused(plan, F, vec4, f);
-    if (rc != HG_OK) return rc;
-    if ((*f)->pmem_entries <= (int64_t)(2.6 * (double)plan->nnz) && (int64_t)(*f)->n_mat * 4 <= plan->M)
-      *variant = HG_VARIANT_FUSED;
-  }
+  const bool small = plan->nnz <= (1 << 18);  // launch-bound: work per launch hardly matters
+  if (!small && plan->small_nnz_frac < 0.2) return HG_OK;  // not worth building the schedule
+  int rc = get_fused(plan, F, vec4, f);
+  if (rc != HG_OK) return rc;
+  const int64_t n_hub = (*f)->n_hub, n_mat = (*f)->n_mat;
+  const bool hubs_ok = n_hub * 16 <= plan->N && (small || !(n_hub > 0 && n_mat * 4 > 3 * (int64_t)plan->M));
+  const bool work_ok = small || (*f)->pmem_entries <= 5 * plan->nnz;
+  if (hubs_ok && work_ok) *variant = HG_VARIANT_FUSED;
   return HG_OK;
 }
 
