@@ -32,7 +32,10 @@ int resolve_opts(const hg_plan_opts *in, hg::Opts &o) {
   if (in) {
     if (in->short_max > 0) o.short_max = in->short_max;
     if (in->split_len > 0) o.split_len = in->split_len;
-    if (in->panel_rows > 0) o.panel_rows = in->panel_rows;
+    if (in->panel_rows > 0) {
+      o.panel_rows = in->panel_rows;
+      o.panel_rows_auto = false;
+    }
     if (in->panel_nnz > 0) o.panel_nnz = in->panel_nnz;
     o.flags = in->flags;
     if (in->t_big > 0) o.t_big = in->t_big;
@@ -205,7 +208,9 @@ int pick_variant(const hg_plan *plan, int32_t F, bool vec4, int32_t *variant,
   int rc = get_fused(plan, F, vec4, f);
   if (rc != HG_OK) return rc;
   const int64_t n_hub = (*f)->n_hub, n_mat = (*f)->n_mat;
-  const bool hubs_ok = n_hub * 16 <= plan->N && (small || !(n_hub > 0 && n_mat * 4 > 3 * (int64_t)plan->M));
+  // small graphs: a hub pass is a third dependent launch, which alone costs more than the pull path
+  const bool hubs_ok = small ? n_hub == 0
+                             : n_hub * 16 <= plan->N && !(n_hub > 0 && n_mat * 4 > 3 * (int64_t)plan->M);
   const bool work_ok = small || (*f)->pmem_entries <= 5 * plan->nnz;
   if (hubs_ok && work_ok) *variant = HG_VARIANT_FUSED;
   return HG_OK;

@@ -106,6 +106,7 @@ struct Opts {
   int32_t short_max = 32;
   int32_t split_len = 512;
   int32_t panel_rows = 128;
+  bool panel_rows_auto = true;  // not set by the caller: small schedules use smaller panels
   int32_t panel_nnz = 1024;
   int32_t flags = 0;
   int32_t t_big = 8;           // fused: recompute hyperedges of at most this many members

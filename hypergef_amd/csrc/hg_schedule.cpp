@@ -139,6 +139,12 @@ void build_sched(int32_t nrows, const int32_t *ptr, const Opts &o, Sched &s) {
   s.n_fix_l1 = 0;
   constexpr int32_t kFixupFan = 32;
   std::vector<Fixup> finals;
+  // A small schedule is latency-bound: a workgroup walks its panel's rows in 8..32 lane groups,
+  // one dependent round of row loads after another, so 128-row panels turn a 2000-row graph into
+  // 16 workgroups doing 16 rounds each (22 us per hop on a 2012-row kNN hypergraph at F = 128).
+  // Unless the caller fixed the size, panels shrink until there are about a thousand of them.
+  int32_t panel_rows = o.panel_rows;
+  if (o.panel_rows_auto) panel_rows = std::max(8, std::min(o.panel_rows, (nrows + 1023) / 1024));
   int32_t start = 0;
   auto close = [&](int32_t end_row) {
     if (end_row > start) {
@@ -177,7 +183,7 @@ void build_sched(int32_t nrows, const int32_t *ptr, const Opts &o, Sched &s) {
             s.fixups.push_back(Fixup{r, first + g * fan, std::min(fan, chunks - g * fan), ++s.nslots});
         }
       }
-    } else if (r - start == o.panel_rows ||
+    } else if (r - start == panel_rows ||
                ptr[r + 1] - ptr[start] > o.panel_nnz) {
       close(r);
       start = r;
