@@ -1,0 +1,10 @@
+#!/bin/bash
+# The end-to-end driver lines kept in profiles/rNN_e2e_driver.csv (training / inference seconds per epoch).
+out=${1:-gpurun_out/e2e_driver.csv}; rm -f $out
+for m in HGNN UniGIN UniGCNII; do for b in hgsys torch; do
+  python tools/hgsys.py --model $m --backend $b --dname cora --epochs 100 --output $out > /dev/null 2>&1
+done; done
+for b in hgsys torch; do python tools/hgsys.py --model HGNN --backend $b --dname pubmed --nhid 128 --epochs 100 --output $out > /dev/null 2>&1; done
+for b in hgsys torch; do python tools/hgsys.py --model HGNN --backend $b --dname cora --replicas 256 --epochs 30 --output $out > /dev/null 2>&1; done
+for b in hgsys torch; do python tools/hgsys.py --model HGNN --backend $b --dname cora --replicas 256 --nhid 64 --nlayer 4 --nfeat 64 --epochs 30 --output $out > /dev/null 2>&1; done
+cat $out
