@@ -205,14 +205,20 @@ int pick_variant(const hg_plan *plan, int32_t F, bool vec4, int32_t *variant,
   *variant = HG_VARIANT_PULL;
   const bool small = plan->nnz <= (1 << 18);  // launch-bound: work per launch hardly matters
   if (!small && plan->small_nnz_frac < 0.2) return HG_OK;  // not worth building the schedule
-  int rc = get_fused(plan, F, vec4, f);
-  if (rc != HG_OK) return rc;
-  const int64_t n_hub = (*f)->n_hub, n_mat = (*f)->n_mat;
+  // hubs first: that part of the rule needs only the classification, not the panels
+  int32_t cap, mem_cap;
+  fused_caps(plan, F, vec4, cap, mem_cap);
+  int64_t n_mat = 0, n_hub = 0;
+  hg::classify_fused(plan->N, plan->M, plan->ptr_t.data(), plan->ptr_v.data(), plan->ind_v.data(), plan->opts,
+                     cap, mem_cap, &n_mat, &n_hub);
   // small graphs: a hub pass is a third dependent launch, which alone costs more than the pull path
   const bool hubs_ok = small ? n_hub == 0
                              : n_hub * 16 <= plan->N && !(n_hub > 0 && n_mat * 4 > 3 * (int64_t)plan->M);
+  if (!hubs_ok) return HG_OK;
+  int rc = get_fused(plan, F, vec4, f);
+  if (rc != HG_OK) return rc;
   const bool work_ok = small || (*f)->pmem_entries <= 5 * plan->nnz;
-  if (hubs_ok && work_ok) *variant = HG_VARIANT_FUSED;
+  if (work_ok) *variant = HG_VARIANT_FUSED;
   return HG_OK;
 }
 

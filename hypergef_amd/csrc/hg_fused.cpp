@@ -14,6 +14,25 @@ namespace hg {
 
 void pack_records(FusedSched &f, int32_t ng, int32_t idle);
 
+// The classification step of build_fused alone (what the AUTO rule needs first): how many
+// vertices would be hubs and how many hyperedges materialised for these capacities.
+void classify_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ptr_v, const int32_t *ind_v,
+                    const Opts &o, int32_t cap, int32_t mem_cap, int64_t *n_mat, int64_t *n_hub) {
+  const int32_t t_big = std::max(1, std::min(o.t_big, mem_cap));
+  const int32_t vdeg_max = std::max(1, std::min(std::min(cap, cap * 2), mem_cap / t_big));
+  std::vector<uint8_t> is_mat((size_t)M, 0);
+  *n_hub = 0;
+  for (int32_t e = 0; e < M; e++)
+    if (ptr_t[e + 1] - ptr_t[e] > t_big) is_mat[e] = 1;
+  for (int32_t v = 0; v < N; v++)
+    if (ptr_v[v + 1] - ptr_v[v] > vdeg_max) {
+      (*n_hub)++;
+      for (int32_t p = ptr_v[v]; p < ptr_v[v + 1]; p++) is_mat[ind_v[p]] = 1;
+    }
+  *n_mat = 0;
+  for (int32_t e = 0; e < M; e++) *n_mat += is_mat[e];
+}
+
 void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_t,
                  const int32_t *ptr_v, const int32_t *ind_v, const Opts &o, int32_t cap,
                  int32_t mem_cap, int32_t ng, FusedSched &f) {

@@ -125,6 +125,8 @@ void transpose_csr(int32_t nrows, int32_t ncols, const int32_t *ptr,
                    const int32_t *ind, std::vector<int32_t> &t_ptr,
                    std::vector<int32_t> &t_ind);
 void build_sched(int32_t nrows, const int32_t *ptr, const Opts &o, Sched &s);
+void classify_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ptr_v, const int32_t *ind_v,
+                    const Opts &o, int32_t cap, int32_t mem_cap, int64_t *n_mat, int64_t *n_hub);
 void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_t,
                  const int32_t *ptr_v, const int32_t *ind_v, const Opts &o, int32_t cap,
                  int32_t mem_cap, int32_t ng, FusedSched &f);
