@@ -95,7 +95,7 @@ void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_
       while (!st.empty()) {
         Frame &fr = st.back();
         bool descended = false;
-        while (fr.ep < ptr_v[fr.v + 1] && !descended) {
+        while (!descended && fr.ep < ptr_v[fr.v + 1]) {  // (fr dangles once descended: test that first)
           const int32_t e = ind_v[fr.ep];
           if (fr.up < 0) {  // first look at this hyperedge from this vertex
             if (seen[e] || is_mat[e]) {
