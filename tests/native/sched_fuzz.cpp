@@ -103,8 +103,55 @@ static void one_graph(std::mt19937 &rng, int N, int M, double mean, int hub_ever
   }
 }
 
-int main() {
+// hg_balance_schedule on random row pointers (size query, then fill) and hg_mtx_read on
+// well-formed, odd and broken MatrixMarket text.
+static void balance_and_mtx(std::mt19937 &rng, const char *tmp_path) {
+  for (int it = 0; it < 60; it++) {
+    const int nrow = (int)(rng() % 200);
+    std::vector<int32_t> ptr(1, 0);
+    for (int r = 0; r < nrow; r++) ptr.push_back(ptr.back() + (int32_t)(rng() % 4 == 0 ? 0 : rng() % 40));
+    const int ngs = 1 + (int)(rng() % 12);
+    int64_t nk = 0, ng = 0;
+    CHECK(hg_balance_schedule(nrow, ngs, ptr.data(), &nk, &ng, nullptr, nullptr, nullptr, nullptr) == HG_OK);
+    std::vector<int32_t> key((size_t)nk + 1), row((size_t)ng + 1), st((size_t)ng + 1), ed((size_t)ng + 1);
+    int64_t nk2 = nk, ng2 = ng;
+    CHECK(hg_balance_schedule(nrow, ngs, ptr.data(), &nk2, &ng2, key.data(), row.data(), st.data(), ed.data()) == HG_OK);
+    CHECK(nk2 == nk && ng2 == ng);
+    for (int64_t g = 0; g < ng; g++) CHECK(row[g] >= 0 && row[g] < nrow && st[g] >= 0 && st[g] + 1 < nk && ed[g] >= 0 && ed[g] + 1 < nk);
+  }
+  const char *texts[] = {
+      "%%MatrixMarket matrix coordinate real general\n% comment\n3 2 4\n1 1 1.0\n2 1 1.0\n3 2 1.0\n1 2 1.0\n",
+      "%%MatrixMarket matrix coordinate pattern symmetric\n3 3 2\n2 1\n3 3\n",
+      "%%MatrixMarket matrix coordinate real general\n3 2 2\n1 1 1.0\n",          // fewer entries than declared
+      "%%MatrixMarket matrix coordinate real general\n3 2 1\n9 1 1.0\n",          // row out of range
+      "%%MatrixMarket matrix coordinate real general\n-3 2 1\n1 1 1.0\n",         // negative size
+      "%%MatrixMarket matrix coordinate real general\n",                           // no size line
+      "garbage\n1 2 3\n",
+      "",
+  };
+  for (const char *t : texts) {
+    FILE *fp = std::fopen(tmp_path, "w");
+    CHECK(fp != nullptr);
+    std::fputs(t, fp);
+    std::fclose(fp);
+    int32_t nr = 0, nc = 0, *hp = nullptr, *hi = nullptr, *tp = nullptr, *ti = nullptr;
+    int64_t nnz = 0;
+    const int rc = hg_mtx_read(tmp_path, &nr, &nc, &nnz, &hp, &hi, &tp, &ti);
+    if (rc == HG_OK) {
+      CHECK(hp && tp && hp[nr] == nnz && tp[nc] == nnz);
+      for (int64_t p = 0; p < nnz; p++) CHECK(hi[p] >= 0 && hi[p] < nc && ti[p] >= 0 && ti[p] < nr);
+      hg_free(hp);
+      hg_free(hi);
+      hg_free(tp);
+      hg_free(ti);
+    }
+  }
+  CHECK(hg_mtx_read("/nonexistent/file.mtx", nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) != HG_OK);
+}
+
+int main(int argc, char **argv) {
   std::mt19937 rng(12345);
+  balance_and_mtx(rng, argc > 1 ? argv[1] : "/tmp/sched_fuzz.mtx");
   for (int it = 0; it < 240; it++) {
     const int N = 1 + (int)(rng() % (it % 20 == 0 ? 4000 : 400)), M = (int)(rng() % (it % 20 == 0 ? 3000 : 300));
     one_graph(rng, N, M, 0.5 + (it % 7) * 2.0, it % 3 == 0 ? 2 : 0, it % 11 == 5);

@@ -285,7 +285,8 @@ def test_models_torch_backend_cpu(hg):
 
 
 def test_schedule_builders_under_sanitizers(tmp_path):
-    """AddressSanitizer + UBSan over the host-side schedule builders on random hypergraphs
+    """AddressSanitizer + UBSan over the host-side code (schedule builders on random hypergraphs,
+    balance_schedule, the MatrixMarket reader on good and broken files)
     (tests/native/sched_fuzz.cpp); CPU build only -- the GPU pool has no sanitizer runs."""
     import shutil
     import subprocess
@@ -296,12 +297,13 @@ def test_schedule_builders_under_sanitizers(tmp_path):
     exe = str(tmp_path / "sched_fuzz")
     src = [os.path.join(root, "tests", "native", "sched_fuzz.cpp"),
            os.path.join(root, "hypergef_amd", "csrc", "hg_schedule.cpp"),
-           os.path.join(root, "hypergef_amd", "csrc", "hg_fused.cpp")]
+           os.path.join(root, "hypergef_amd", "csrc", "hg_fused.cpp"),
+           os.path.join(root, "hypergef_amd", "csrc", "hg_mtx.cpp")]
     cc = subprocess.run([gxx, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
                          "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "hypergef_amd", "csrc"),
                          "-o", exe] + src, capture_output=True, text=True)
     if cc.returncode != 0 and "sanitize" in cc.stderr:
         pytest.skip("g++ has no sanitizer runtime here")
     assert cc.returncode == 0, cc.stderr[-2000:]
-    run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    run = subprocess.run([exe, str(tmp_path / "fuzz.mtx")], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0 and "sched_fuzz ok" in run.stdout, (run.stdout + run.stderr)[-3000:]
