@@ -572,3 +572,41 @@ def _linear_autograd_cases(hg, hyperg, inc, cases):
         assert torch.allclose(Y, Y_ref, rtol=1e-4, atol=1e-5)
         assert torch.allclose(gx, gx_ref, rtol=1e-4, atol=1e-5)
         assert torch.allclose(gw, gw_ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("shape", ["cora", "pubmed", "powerlaw", "ragged"])
+def test_outputs_stay_inside_their_buffers(hg, oracle, shape):
+    """Y, the workspace and (linear path) the projected output sit between sentinel-filled guard
+    bands: nothing outside the documented extents may be written, whatever the variant."""
+    from hypergef_amd.plan import Plan
+    from hypergef_amd import _lib
+    inc = _make(shape)
+    ptr, ind = _dev(inc.csrptr), _dev(inc.colind)
+    plan = Plan.from_tensors(inc.N, ptr, ind)
+    G = 4096  # guard floats on each side
+    for F in (32, 20, 64):
+        X = torch.rand(inc.N, F, device=DEV)
+        nws = (plan.workspace_bytes(F) + 3) // 4
+        for variant in ("pull", "fused", "push_atomic"):
+            ybuf = torch.full((G + inc.N * F + G,), 7.25, device=DEV)
+            wbuf = torch.full((G + nws + G,), 7.25, device=DEV)
+            Y = ybuf[G:G + inc.N * F].view(inc.N, F)
+            ws = wbuf[G:G + nws].view(torch.uint8)
+            if variant == "push_atomic":
+                Y.zero_()
+            plan.aggregate(ptr, ind, X, variant=variant, out=Y, workspace=ws)
+            torch.cuda.synchronize()
+            for buf, n in ((ybuf, inc.N * F), (wbuf, nws)):
+                assert bool((buf[:G] == 7.25).all()) and bool((buf[G + n:] == 7.25).all()), (shape, F, variant)
+        if F in (32, 64):
+            F_out = 48
+            Wl = torch.randn(F_out, F, device=DEV) / F ** 0.5
+            nws = (int(_lib.lib().hg_aggr_linear_workspace_bytes(plan._h, F)) + 3) // 4
+            for variant in ("pull", "fused"):
+                ybuf = torch.full((G + inc.N * F_out + G,), 7.25, device=DEV)
+                wbuf = torch.full((G + nws + G,), 7.25, device=DEV)
+                Y = ybuf[G:G + inc.N * F_out].view(inc.N, F_out)
+                plan.aggregate_linear(ptr, ind, X, Wl, variant=variant, out=Y, workspace=wbuf[G:G + nws].view(torch.uint8))
+                torch.cuda.synchronize()
+                for buf, n in ((ybuf, inc.N * F_out), (wbuf, nws)):
+                    assert bool((buf[:G] == 7.25).all()) and bool((buf[G + n:] == 7.25).all()), (shape, F, variant)
