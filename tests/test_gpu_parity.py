@@ -610,3 +610,26 @@ def test_outputs_stay_inside_their_buffers(hg, oracle, shape):
                 torch.cuda.synchronize()
                 for buf, n in ((ybuf, inc.N * F_out), (wbuf, nws)):
                     assert bool((buf[:G] == 7.25).all()) and bool((buf[G + n:] == 7.25).all()), (shape, F, variant)
+
+
+@pytest.mark.parametrize("dname", list(synth.ALLSET_SHAPES))
+def test_reference_test_contract_all_dataset_shapes(hg, oracle, dname):
+    """The reference's only Python test (test/hgnn_test.py:65-92), shape for shape: for each of
+    its 13 datasets (synthetic stand-ins of the nominal sizes) HGNNAggr on randn(N, 2) features
+    with Wdiag = ones against HGNN_check, torch.allclose(rtol=1e-4, atol=1e-6) -- plus this
+    repo's tighter bound, and F = 32 as the benchmark width."""
+    inc = synth.allset_shape(dname)
+    hyperg = hg.HyperGraph.from_incidence(inc, DEV, ngs=1 << 30)
+    H_ptr, H_ind = vertex_csr(inc, oracle)
+    degE, degV = oracle.degrees(inc.N, inc.M, inc.csrptr, inc.colind)
+    degE0 = np.where(np.isinf(degE), 0, degE).astype(np.float32)
+    torch.manual_seed(1)
+    for F in (2, 32):
+        X = torch.randn(inc.N, F)
+        Wdiag = torch.ones(inc.M, 1, device=DEV)
+        out = hg.HGNNAggr(hyperg, X.to(DEV), hyperg.degE, hyperg.degV, Wdiag)  # 5-argument call, as the test does
+        ref = oracle.hgnn_check(inc.N, inc.M, F, H_ptr, H_ind, inc.csrptr, inc.colind, X.numpy(), degE0, degV,
+                                np.ones(inc.M, np.float32))
+        assert torch.allclose(out.cpu(), torch.from_numpy(ref), rtol=1e-4, atol=1e-6)
+        if inc.nnz < 100000:  # hub rows of the two big shapes are summed in another order
+            _assert_close(out, ref)
