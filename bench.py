@@ -306,6 +306,24 @@ def main():
             out["allreduce_dense"] = {"ms_per_step": float(t.item()) / n_ar * 1e3,
                                       "value": total_nnz * n_ar / float(t.item()),
                                       "bytes_allreduced": inc.N * world * F * 4}
+            if not args.share_gpu:  # gloo has no reduce_scatter
+                # SURVEY 8(e) option ii: the sum scattered, each rank keeps 1/world of the rows
+                Yrs = torch.empty((inc.N, F), dtype=torch.float32, device=dev)
+
+                def step_rs():
+                    plan.aggregate(ptr, ind, X, degE, degV, W, variant=args.variant, out=Y, workspace=ws)
+                    Yg[rank * inc.N:(rank + 1) * inc.N].copy_(Y)
+                    dist.reduce_scatter_tensor(Yrs, Yg)
+                try:  # an extra: never let it take the headline line down with it
+                    for _ in range(3):
+                        step_rs()
+                    w_rs, _ = timed_steps(step_rs, n_ar, sync, barrier)
+                    t = torch.tensor([w_rs], dtype=torch.float64, device=dev)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    out["reduce_scatter_dense"] = {"ms_per_step": float(t.item()) / n_ar * 1e3,
+                                                   "value": total_nnz * n_ar / float(t.item())}
+                except Exception as exc:
+                    out["reduce_scatter_dense"] = {"error": str(exc)[:200]}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(base, inc, F, X_host)

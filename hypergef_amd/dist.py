@@ -7,6 +7,9 @@ and degV replicated, aggregates its own hyperedges into a dense partial
 Y_r [N, F], and one sum all-reduce over RCCL (backend "nccl" on ROCm) yields Y
 on every rank:  Y = sum_r degV . H_r (degE_r . W_r . (H_r^T X)).
 
+`exchange="reduce_scatter"` (SURVEY.md 8(e) option ii) moves half the bytes: the sum is
+scattered, rank r ends with rows `row_range(r)` of Y only -- what a row-parallel next layer needs.
+
 When no vertex is shared between shards (a batch of independent hypergraphs
 sharded by graph) the partials have disjoint row support; `exchange="none"`
 then skips the collective and leaves Y row-sharded (each rank owns the rows of
@@ -61,6 +64,8 @@ class ShardedAggregator:
         self.local = local_incidence(inc, self.lo, self.hi)
         self.N, self.M = inc.N, inc.M
         self.device = device
+        if exchange not in ("allreduce", "reduce_scatter", "none"):
+            raise ValueError("exchange must be 'allreduce', 'reduce_scatter' or 'none'")
         self.exchange = exchange
         self._local_op = local_op or self._hip_local_op
         self._hip = None
@@ -83,4 +88,28 @@ class ShardedAggregator:
                            None if degV is None else degV.reshape(-1), self.slice_edge_vector(W))
         if self.exchange == "allreduce" and self.world > 1:
             dist.all_reduce(Y, op=dist.ReduceOp.SUM)
+        elif self.exchange == "reduce_scatter":
+            return self._reduce_scatter(Y)
         return Y
+
+    def row_range(self, rank=None):
+        """Rows of Y that `exchange="reduce_scatter"` leaves on `rank`: equal blocks of
+        ceil(N / world) rows, the last one short."""
+        rank = self.rank if rank is None else rank
+        blk = -(-self.N // self.world)
+        return min(rank * blk, self.N), min((rank + 1) * blk, self.N)
+
+    def _reduce_scatter(self, Y):
+        lo, hi = self.row_range()
+        if self.world == 1:
+            return Y
+        blk = -(-self.N // self.world)
+        F = Y.shape[1]
+        if dist.get_backend() == "gloo":  # no reduce_scatter in gloo (CPU tests): same result, more bytes
+            dist.all_reduce(Y, op=dist.ReduceOp.SUM)
+            return Y[lo:hi].contiguous()
+        pad = blk * self.world - self.N
+        src = Y if pad == 0 else torch.cat([Y, Y.new_zeros((pad, F))])
+        out = Y.new_empty((blk, F))
+        dist.reduce_scatter_tensor(out, src, op=dist.ReduceOp.SUM)
+        return out[:hi - lo]

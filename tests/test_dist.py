@@ -79,6 +79,12 @@ def _worker(rank, world, port, out_dir):
     tot = part.clone()
     dist.all_reduce(tot)
     np.testing.assert_allclose(tot.numpy(), ref, rtol=1e-5, atol=1e-6)
+    # exchange="reduce_scatter": each rank ends with its block of rows of the sum
+    rs = ShardedAggregator(inc, local_op=local_op, exchange="reduce_scatter")
+    rows = rs.aggregate(torch.from_numpy(X), torch.from_numpy(degE), torch.from_numpy(degV), torch.from_numpy(W))
+    lo, hi = rs.row_range()
+    assert rows.shape == (hi - lo, F) and rs.row_range(world - 1)[1] == inc.N and rs.row_range(0)[0] == 0
+    np.testing.assert_allclose(rows.numpy(), ref[lo:hi], rtol=1e-5, atol=1e-6)
     open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
     dist.destroy_process_group()
 
