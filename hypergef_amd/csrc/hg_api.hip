@@ -200,8 +200,32 @@ Carve carve(const hg_plan *p, int32_t F) {
 // 0-35 % on large batches even when every hyperedge lands in four panels or 60 % of them are
 // materialised -- and lose only where hubs drag nearly every hyperedge into the materialised
 // table (yelp, the power-law config): the fused path is then the pull path plus overhead.
+int pick_variant_uncached(const hg_plan *plan, int32_t F, bool vec4, int32_t *variant,
+                          const hg::FusedSched **f);
+
 int pick_variant(const hg_plan *plan, int32_t F, bool vec4, int32_t *variant,
                  const hg::FusedSched **f) {
+  // decided once per feature width: the classification below walks the whole graph on the host
+  hg_plan *mp = const_cast<hg_plan *>(plan);
+  const int64_t key = (int64_t)F * 2 + (vec4 ? 1 : 0);
+  {
+    std::lock_guard<std::mutex> lock(mp->auto_mu);
+    auto it = mp->auto_choice.find(key);
+    if (it != mp->auto_choice.end()) {
+      *variant = it->second;
+      return *variant == HG_VARIANT_FUSED ? get_fused(plan, F, vec4, f) : HG_OK;
+    }
+  }
+  int rc = pick_variant_uncached(plan, F, vec4, variant, f);
+  if (rc == HG_OK) {
+    std::lock_guard<std::mutex> lock(mp->auto_mu);
+    mp->auto_choice[key] = *variant;
+  }
+  return rc;
+}
+
+int pick_variant_uncached(const hg_plan *plan, int32_t F, bool vec4, int32_t *variant,
+                          const hg::FusedSched **f) {
   *variant = HG_VARIANT_PULL;
   const bool small = plan->nnz <= (1 << 18);  // launch-bound: work per launch hardly matters
   if (!small && plan->small_nnz_frac < 0.2) return HG_OK;  // not worth building the schedule

@@ -143,6 +143,8 @@ struct hg_plan {
   hg::Sched sched[2];  // [0]: H_T rows = hyperedges, [1]: H rows = vertices
   std::map<int64_t, hg::FusedSched> fused;  // keyed by (slot, entry) capacity: depends on F
   std::mutex fused_mu;
+  std::map<int64_t, int32_t> auto_choice;  // what HG_VARIANT_AUTO resolved to, keyed by (F, vec4)
+  std::mutex auto_mu;
   double small_nnz_frac = 0.0;  // share of incidences in hyperedges of <= t_big members
   int64_t device_bytes = 0;
   int device = -1;

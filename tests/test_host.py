@@ -307,3 +307,18 @@ def test_schedule_builders_under_sanitizers(tmp_path):
     assert cc.returncode == 0, cc.stderr[-2000:]
     run = subprocess.run([exe, str(tmp_path / "fuzz.mtx")], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0 and "sched_fuzz ok" in run.stdout, (run.stdout + run.stderr)[-3000:]
+
+
+def test_auto_variant_decision_is_cached(hg):
+    """HG_VARIANT_AUTO is resolved on every aggregation call: after the first call for a feature
+    width it must cost nothing (it once re-walked the whole graph per call: 1 ms on the bench batch)."""
+    import time
+    from hypergef_amd import plan as planmod
+    inc = synth.replicate_block_diagonal(synth.cora_shape(), 128)
+    plan = planmod.Plan.from_host(inc.N, inc.M, inc.csrptr, inc.colind, planmod.make_opts(host_only=True))
+    first = plan.auto_variant(32)
+    t0 = time.perf_counter()
+    for _ in range(200):
+        assert plan.auto_variant(32) == first
+    per_call = (time.perf_counter() - t0) / 200
+    assert per_call < 50e-6, "auto variant costs %.1f us per call" % (per_call * 1e6)
