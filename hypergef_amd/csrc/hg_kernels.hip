@@ -21,6 +21,9 @@ template <> struct Vec<1> {
   float x;
   __device__ __forceinline__ static Vec zero() { return Vec{0.f}; }
   __device__ __forceinline__ static Vec load(const float *p) { return Vec{*p}; }
+  __device__ __forceinline__ static Vec load_buf(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return Vec{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0))};
+  }
   __device__ __forceinline__ void store(float *p) const { *p = x; }
   __device__ __forceinline__ void store_nt(float *p) const { __builtin_nontemporal_store(x, p); }
   __device__ __forceinline__ void add(const Vec &o) { x += o.x; }
@@ -32,6 +35,10 @@ template <> struct Vec<4> {
   __device__ __forceinline__ static Vec zero() { return Vec{make_float4(0.f, 0.f, 0.f, 0.f)}; }
   __device__ __forceinline__ static Vec load(const float *p) {
     return Vec{*reinterpret_cast<const float4 *>(p)};
+  }
+  __device__ __forceinline__ static Vec load_buf(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    return Vec{__builtin_bit_cast(float4, (u4)__builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0))};
   }
   __device__ __forceinline__ void store(float *p) const { *reinterpret_cast<float4 *>(p) = v; }
   __device__ __forceinline__ void store_nt(float *p) const {
@@ -508,7 +515,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KSTEPS >= 3
 typedef unsigned hg_u4 __attribute__((ext_vector_type(4)));
 typedef int hg_i4 __attribute__((ext_vector_type(4)));
 
-// FAST (VEC = 4 only): rows are fetched with buffer_load_dwordx4 through a buffer
+// FAST: rows are fetched with buffer_load_dwordx4 (VEC = 1: buffer_load_dword) through a buffer
 // descriptor and a 32-bit byte offset formed by one v_mad_u32_u24 (row * row_bytes +
 // column bytes) instead of 64-bit pointer arithmetic; needs N < 2^24, F*4 < 2^24 and
 // tables below 2 GiB (the launcher checks; otherwise FAST = false runs the same loop
@@ -613,15 +620,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LIN ? (LPR 
         }
         if constexpr (FAST) {
           const unsigned off = __umul24((unsigned)ent[j], row_bytes) + col_off;  // flags sit above bit 23
-          hg_u4 q;
           if constexpr (MAT) {
             const bool mat = (ent[j] & 0x40000000) != 0;
-            q = __builtin_amdgcn_raw_buffer_load_b128(rx, mat ? 0x80000000u : off, 0, 0);
-            if (mat) q = __builtin_amdgcn_raw_buffer_load_b128(rm, off, 0, 0);
+            v[j] = V::load_buf(rx, mat ? 0x80000000u : off);
+            if (mat) v[j] = V::load_buf(rm, off);
           } else {
-            q = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+            v[j] = V::load_buf(rx, off);
           }
-          v[j].v = __builtin_bit_cast(float4, q);
         } else {
           const bool on = col_ok && ent[j] != idle && !(DBG && (a.debug & 1));
           const int64_t idx = ent[j] & 0x3fffffff;
@@ -890,6 +895,18 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
     }
   }
   if (a.Wlin) return hipErrorInvalidValue;
+  if constexpr (VEC == 1 && LPR >= 8) {  // F >= 5, not a multiple of 4 (class-count widths): the same buffer-load
+                                          // loop, one dword per lane (+7-20 % at F = 7, 33; narrower rows: no gain)
+    const bool fast = t.fused_fast && !t.fused_debug && a.x_bytes > 0 && a.nrows_x < (1 << 24) && a.F < (1 << 22) &&
+                      (!a.Xe_mat || a.mat_bytes > 0);
+    if (fast) {
+      if (!a.Xe_mat && !a.degE && !a.W)
+        hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 8, true, false, false, false>), grid, dim3(256), lds_p, stream, ad);
+      else
+        hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 8, true, true, true, false>), grid, dim3(256), lds_p, stream, ad);
+      return hipGetLastError();
+    }
+  }
   hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 8, false, true, true, true>), grid, dim3(256), lds_p, stream, ad);
   return hipGetLastError();
 }
