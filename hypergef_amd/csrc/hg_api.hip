@@ -626,6 +626,7 @@ struct LinReq {
   int32_t F_out;
   float *Y;
   bool done;
+  hg::LinEpilogue epi;
 };
 
 static int aggr_impl(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
@@ -703,6 +704,7 @@ static int aggr_impl(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
     if (lin && f->n_hub == 0 && vec4) {  // hub rows are produced outside the panels: no epilogue then
       a.Wlin = lin->Wlin;
       a.F_out = lin->F_out;
+      a.epi = lin->epi;
       if (hg::fused_linear_ok(a)) {
         a.Y = lin->Y;
         lin->done = true;
@@ -773,10 +775,11 @@ size_t hg_aggr_linear_workspace_bytes(const hg_plan *plan, int32_t F_in) {
   return hg_plan_workspace_bytes(plan, F_in) + round256((size_t)plan->N * F_in * sizeof(float));
 }
 
-int hg_aggr_linear_f32(const hg_plan *plan, int32_t F_in, int32_t F_out, const int32_t *csrptr_t,
-                       const int32_t *colind_t, const float *X, const float *degE, const float *degV,
-                       const float *W, const float *wfrag, float *Y, void *workspace,
-                       size_t workspace_bytes, int32_t variant, hg_stream_t stream) {
+int hg_aggr_linear_res_f32(const hg_plan *plan, int32_t F_in, int32_t F_out, const int32_t *csrptr_t,
+                           const int32_t *colind_t, const float *X, const float *degE, const float *degV,
+                           const float *W, const float *wfrag, const float *R, float ca, float cb, int32_t relu,
+                           float *T_out, float *Y, void *workspace, size_t workspace_bytes, int32_t variant,
+                           hg_stream_t stream) {
   if (!plan || !wfrag || !Y) {
     hg::set_error("hg_aggr_linear_f32: null argument");
     return HG_ERR_INVALID;
@@ -794,12 +797,17 @@ int hg_aggr_linear_f32(const hg_plan *plan, int32_t F_in, int32_t F_out, const i
     hg::set_error("hg_aggr_linear_f32: workspace smaller than hg_aggr_linear_workspace_bytes");
     return HG_ERR_WORKSPACE;
   }
-  if (!aligned16(wfrag) || !aligned16(Y)) {
-    hg::set_error("hg_aggr_linear_f32: wfrag and Y must be 16-byte aligned");
+  if (!aligned16(wfrag) || !aligned16(Y) || !aligned16(R) || !aligned16(T_out)) {
+    hg::set_error("hg_aggr_linear_f32: wfrag, R, T_out and Y must be 16-byte aligned");
     return HG_ERR_INVALID;
   }
   float *T = reinterpret_cast<float *>(static_cast<char *>(workspace) + round256(base));
-  LinReq lin{wfrag, F_out, Y, false};
+  LinReq lin{wfrag, F_out, Y, false, {}};
+  lin.epi.R = R;
+  lin.epi.ca = ca;
+  lin.epi.cb = R ? cb : 0.f;
+  lin.epi.relu = relu ? 1 : 0;
+  lin.epi.T_out = T_out;
   int rc = aggr_impl(plan, F_in, csrptr_t, colind_t, X, degE, degV, W, T, workspace, base, variant, stream, &lin);
   if (rc != HG_OK || lin.done) return rc;
   hg::LinearArgs la;
@@ -810,9 +818,18 @@ int hg_aggr_linear_f32(const hg_plan *plan, int32_t F_in, int32_t F_out, const i
   la.nrows = plan->N;
   la.F_in = F_in;
   la.F_out = F_out;
+  la.epi = lin.epi;
   hipError_t e = hg::launch_linear(la, static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return hip_fail("linear_rows launch", e);
   return HG_OK;
+}
+
+int hg_aggr_linear_f32(const hg_plan *plan, int32_t F_in, int32_t F_out, const int32_t *csrptr_t,
+                       const int32_t *colind_t, const float *X, const float *degE, const float *degV,
+                       const float *W, const float *wfrag, float *Y, void *workspace,
+                       size_t workspace_bytes, int32_t variant, hg_stream_t stream) {
+  return hg_aggr_linear_res_f32(plan, F_in, F_out, csrptr_t, colind_t, X, degE, degV, W, wfrag, nullptr, 1.f, 0.f,
+                                0, nullptr, Y, workspace, workspace_bytes, variant, stream);
 }
 
 }  // extern "C"

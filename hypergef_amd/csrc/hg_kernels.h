@@ -26,6 +26,18 @@ struct GatherArgs {
   int32_t xcd_remap;
 };
 
+// What happens to an aggregated row t = Aggr(X)[v] on its way through the linear epilogue:
+//   t' = ca * t + cb * R[v]   (R null: t' = ca * t),   T_out[v] = t' if wanted,
+//   Y[v] = act(t' * Wlin^T),  act = relu or identity.
+// One UniGCNII layer ((1-a) Xv + a X0, then (1-b) Xi + b W(Xi), relu: model/ugsys/unigcnii.py:19-21,
+// model/gnn.py:196-199) or UniGIN layer ((1+eps) W(X) + Aggr(W(X)): unigin.py:20-22) is one such pass.
+struct LinEpilogue {
+  const float *R = nullptr;
+  float ca = 1.f, cb = 0.f;
+  int32_t relu = 0;
+  float *T_out = nullptr;
+};
+
 struct FusedArgs {
   int32_t npanels;
   const int32_t *rec;     // packed per-panel records (hg_fused.cpp, pack_records)
@@ -46,6 +58,7 @@ struct FusedArgs {
   // fused linear epilogue (hg_aggr_linear_f32): Y[N, F_out] = (aggregated rows) * Wlin^T
   const float *Wlin = nullptr;  // Wlin [F_out, F] in MFMA fragment order (launch_linear_pack), or null
   int32_t F_out = 0;
+  LinEpilogue epi;
 };
 
 // Y[rowmap ? rowmap[r] : r, :] = T[r, :] * Wlin^T for r < nrows; T is [nrows, F_in] row-major.
@@ -56,6 +69,7 @@ struct LinearArgs {
   float *Y;
   int64_t nrows;
   int32_t F_in, F_out;
+  LinEpilogue epi;
 };
 
 struct PushArgs {

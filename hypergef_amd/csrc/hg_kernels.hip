@@ -390,7 +390,7 @@ __device__ __forceinline__ void mfma_rows_n(int n, const float *t, int ld, int r
 template <int KSTEPS, int NPW>
 __device__ __forceinline__ void panel_times_wt_staged(float *t, int nrows, int F_out, const float *Wlin,
                                                       const int32_t *rowmap, int64_t row0, float *Y, int tid,
-                                                      float (&bv)[KSTEPS]) {
+                                                      float (&bv)[KSTEPS], int relu) {
   constexpr int K = KSTEPS * 4, LD = K + 4, RPN = 4 / NPW;  // row tiles per column tile and wave
   const int lane = tid & 63;
   const int NT = F_out >> 4, RT = (nrows + 15) >> 4;
@@ -429,20 +429,22 @@ __device__ __forceinline__ void panel_times_wt_staged(float *t, int nrows, int F
   for (int i = tid; i < nrows * q; i += 256) {
     const int r = i / q, c = (i - r * q) * 4;
     const int64_t yrow = rowmap ? (int64_t)rowmap[r] : row0 + r;
-    *reinterpret_cast<float4 *>(Y + yrow * F_out + c) = *reinterpret_cast<const float4 *>(t + r * LD + c);
+    float4 o = *reinterpret_cast<const float4 *>(t + r * LD + c);
+    if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+    *reinterpret_cast<float4 *>(Y + yrow * F_out + c) = o;
   }
 }
 
 template <int KSTEPS>
 __device__ __forceinline__ void panel_times_wt(float *t, int nrows, int F_out, const float *Wlin,
                                                const int32_t *rowmap, int64_t row0, float *Y, int tid,
-                                               float (&bv)[KSTEPS]) {
+                                               float (&bv)[KSTEPS], int relu) {
   constexpr int K = KSTEPS * 4, LD = K + 4;
   const int nt_all = F_out >> 4, nwr = nt_all >= 3 ? 1 : 4 / nt_all;  // as lin_split
   const int rt_per_wave = (((nrows + 15) >> 4) + nwr - 1) / nwr;
   if (F_out <= K && rt_per_wave <= (F_out > 64 ? 2 : 4)) {  // workgroup-uniform
-    if (F_out > 64) panel_times_wt_staged<KSTEPS, 2>(t, nrows, F_out, Wlin, rowmap, row0, Y, tid, bv);
-    else panel_times_wt_staged<KSTEPS, 1>(t, nrows, F_out, Wlin, rowmap, row0, Y, tid, bv);
+    if (F_out > 64) panel_times_wt_staged<KSTEPS, 2>(t, nrows, F_out, Wlin, rowmap, row0, Y, tid, bv, relu);
+    else panel_times_wt_staged<KSTEPS, 1>(t, nrows, F_out, Wlin, rowmap, row0, Y, tid, bv, relu);
     return;
   }
   // wider output than input: results go straight to Y, 64 bytes per row and instruction
@@ -463,7 +465,7 @@ __device__ __forceinline__ void panel_times_wt(float *t, int nrows, int F_out, c
 #pragma unroll
           for (int i = 0; i < 4; i++) {
             const int r = (rt + j * sp.rt_step) * 16 + 4 * (lane >> 4) + i;
-            if (r < nrows) ycol[(rowmap ? (int64_t)rowmap[r] : row0 + r) * F_out] = acc[j][i];
+            if (r < nrows) ycol[(rowmap ? (int64_t)rowmap[r] : row0 + r) * F_out] = relu ? fmaxf(acc[j][i], 0.f) : acc[j][i];
           }
         }
     }
@@ -492,6 +494,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KSTEPS >= 3
     const int i = threadIdx.x + j * 256, r = i / (K / 4), c = (i % (K / 4)) * 4;
     v[j] = r < nrows ? *reinterpret_cast<const float4 *>(a.T + (row0 + r) * K + c) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  if (a.epi.R || a.epi.ca != 1.f || a.epi.T_out) {  // t' = ca * t + cb * R[row]
+#pragma unroll
+    for (int j = 0; j < NL; j++) {
+      const int i = threadIdx.x + j * 256, r = i / (K / 4), c = (i % (K / 4)) * 4;
+      if (r >= nrows) continue;
+      const int64_t grow = a.rowmap ? (int64_t)a.rowmap[row0 + r] : row0 + r;
+      float4 t4 = v[j];
+      t4 = make_float4(t4.x * a.epi.ca, t4.y * a.epi.ca, t4.z * a.epi.ca, t4.w * a.epi.ca);
+      if (a.epi.R) {
+        const float4 rr = *reinterpret_cast<const float4 *>(a.epi.R + grow * K + c);
+        t4 = make_float4(t4.x + rr.x * a.epi.cb, t4.y + rr.y * a.epi.cb, t4.z + rr.z * a.epi.cb, t4.w + rr.w * a.epi.cb);
+      }
+      if (a.epi.T_out) *reinterpret_cast<float4 *>(a.epi.T_out + grow * K + c) = t4;
+      v[j] = t4;
+    }
+  }
 #pragma unroll
   for (int j = 0; j < NL; j++) {
     const int i = threadIdx.x + j * 256, r = i / (K / 4), c = (i % (K / 4)) * 4;
@@ -499,7 +517,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KSTEPS >= 3
   }
   __syncthreads();
   panel_times_wt<KSTEPS>(t, nrows, a.F_out, a.Wlin, a.rowmap ? a.rowmap + row0 : nullptr, row0, a.Y,
-                         threadIdx.x, bv);
+                         threadIdx.x, bv, a.epi.relu);
 }
 
 // Packed form of the fused panel kernel.  The plan hands every panel over as ONE
@@ -670,6 +688,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LIN ? (LPR 
         if (a.degV && pe > pb) outr[i].mul(sdeg[r]);
       }
     }
+    if (a.epi.R || a.epi.ca != 1.f) {  // t' = ca * t + cb * R[v]  (workgroup-uniform)
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        if (r0 + i < r1) {
+          outr[i].mul(a.epi.ca);
+          if (a.epi.R) {
+            V rr = V::load(a.epi.R + (int64_t)prow[r0 + i] * F + col);
+            rr.mul(a.epi.cb);
+            outr[i].add(rr);
+          }
+        }
+    }
     // the B fragments of this wave's first column tile: in flight across the two barriers below
     // (issued before hop 2 they would hold K/4 more registers through it: 78 instead of 64 VGPRs)
     float bv[TW / 4];
@@ -689,7 +719,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LIN ? (LPR 
       }
       return;
     }
-    panel_times_wt<TW / 4>(tile, nrows, a.F_out, a.Wlin, prow, 0, a.Y, tid, bv);
+    if (a.epi.T_out) {  // the combined rows themselves, for the backward pass (dWlin needs them)
+      constexpr int q = TW >> 2;
+      for (int i = tid; i < nrows * q; i += 256) {
+        const int r = i / q, c = (i - r * q) * 4;
+        *reinterpret_cast<float4 *>(a.epi.T_out + (int64_t)prow[r] * TW + c) =
+            *reinterpret_cast<const float4 *>(tile + r * (TW + 4) + c);
+      }
+    }
+    panel_times_wt<TW / 4>(tile, nrows, a.F_out, a.Wlin, prow, 0, a.Y, tid, bv, a.epi.relu);
   } else if (!(DBG && (a.debug & 8))) {  // ---- hop 2
     const int rpg = (nrows + NG - 1) / NG;
     const int r0 = min(g * rpg, nrows), r1 = min(r0 + rpg, nrows);

@@ -49,6 +49,10 @@ class HyperGsysUinGINConv(nn.Module):
         self.eps = nn.parameter.Parameter(torch.FloatTensor([0]))
 
     def forward(self, X):
+        if ops._STATE["variant"] in ("auto", "pull", "fused") and ops.linear_fusion_pays(X.shape[1], self.W.weight.shape[0]):
+            # (1 + eps) W(X) + Aggr(W(X)) = ((1 + eps) X + Aggr(X)) . W^T: the whole layer in one pass
+            return ops.aggr_res_linear(self.hyperg.H_T_csrptr, self.hyperg.H_T_colind, X, self.W.weight,
+                                       residual=X, ca=1.0, cb=1 + self.eps.reshape(()))
         X = self.W(X)
         Xv = UniGNNConv(self.hyperg, X)
         return (1 + self.eps) * X + Xv
@@ -61,10 +65,19 @@ class HyperGsysUniGCNII(nn.Module):
         self.heads, self.in_channels, self.out_channels = heads, in_channels, out_channels
         self.hyperg, self.degE, self.degV = hyperg, hyperg.degE, hyperg.degV
 
-    def forward(self, X, X0, alpha, beta):
+    def forward(self, X, X0, alpha, beta, relu=False):
+        F = X.shape[1]
+        if ops._STATE["variant"] in ("auto", "pull", "fused") and ops.linear_fusion_pays(F, self.W.weight.shape[0]) \
+                and self.W.weight.shape[0] == F:
+            # Xi = (1 - alpha) Xv + alpha X0;  (1 - beta) Xi + beta W(Xi) = Xi . ((1 - beta) I + beta W)^T:
+            # aggregation, both mixes, the projection and the model's relu in one pass
+            M = (1 - beta) * torch.eye(F, device=X.device, dtype=X.dtype) + beta * self.W.weight
+            return ops.aggr_res_linear(self.hyperg.H_T_csrptr, self.hyperg.H_T_colind, X, M, residual=X0,
+                                       ca=1 - alpha, cb=alpha, degE=self.degE, degV=self.degV, relu=relu)
         Xv = UniGNNConvdeg(self.hyperg, X, self.degE, self.degV)
         Xi = (1 - alpha) * Xv + alpha * X0
-        return (1 - beta) * Xi + beta * self.W(Xi)
+        out = (1 - beta) * Xi + beta * self.W(Xi)
+        return torch.relu(out) if relu else out
 
 
 # ---- torch index_add baseline (model/pygnn/*.py formulas) ---------------------
@@ -183,6 +196,9 @@ class UniGCNII(nn.Module):
         for i, con in enumerate(self.convs[1:-1]):
             x = self.dropout(x)
             beta = math.log(lamda / (i + 1) + 1)
-            x = F.relu(con(x, x0, alpha, beta))
+            if isinstance(con, HyperGsysUniGCNII):
+                x = con(x, x0, alpha, beta, relu=True)  # the relu rides in the layer's epilogue
+            else:
+                x = F.relu(con(x, x0, alpha, beta))
         x = self.dropout(x)
         return F.log_softmax(self.convs[-1](x), dim=1)

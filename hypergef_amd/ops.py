@@ -27,7 +27,11 @@ from . import _lib
 from .plan import (Plan, cached_plan, linear_fusion_pays, linear_rows, linear_supported, _check_feat,
                    _check_index, _ptr, _stream_handle)
 
+import os as _os
+
 _STATE = {"variant": "auto", "backward": "reference", "fuse_linear": "auto"}
+if _os.environ.get("HG_FUSE_LINEAR") in ("auto", "always", "never"):  # A/B runs of the drivers
+    _STATE["fuse_linear"] = _os.environ["HG_FUSE_LINEAR"]
 
 
 def set_variant(name):
@@ -170,6 +174,80 @@ class _SumAggrLinear(torch.autograd.Function):
         gx = dZ @ weight if ctx.needs_input_grad[2] else None
         gw = dZ.t() @ node_feat if ctx.needs_input_grad[3] else None
         return None, None, gx, gw, None, None, None
+
+
+class _AggrResLinear(torch.autograd.Function):
+    """Y = act((ca * Aggr(X) + cb * R) . M^T): a whole UniGNN layer as one node
+    (hg_aggr_linear_res_f32).  UniGCNII (model/ugsys/unigcnii.py:19-21 + the relu of model/gnn.py:199):
+    ca = 1 - alpha, cb = alpha, R = X0, M = (1 - beta) I + beta W.  UniGIN (unigin.py:20-22):
+    ca = 1, cb = 1 + eps, R = X, M = W.  Falls back to the same formula in torch ops around the
+    plain aggregation where the MFMA epilogue does not take the widths.  Backward: dP = dY (masked by
+    the relu), dT = dP . M, dM = dP^T . T, dX = ca * (aggregation backward of dT), dR = cb * dT,
+    dcb = <dT, R> (cb may be a tensor, e.g. 1 + eps)."""
+
+    @staticmethod
+    def forward(ctx, csrptr_t, indices_t, node_feat, M, R, cb, degE, degV, W, ca, relu):
+        _check_feat(node_feat, "node_feat")
+        _check_index(csrptr_t, "csrptr_t")
+        _check_index(indices_t, "indices_t")
+        degE, degV, W = _flat(degE), _flat(degV), _flat(W)
+        N, F_in = node_feat.shape
+        F_out = M.shape[0]
+        cbf = float(cb) if R is not None else 0.0
+        variant = _STATE["variant"] if _STATE["variant"] != "push_groups" else "auto"
+        need_t = any(ctx.needs_input_grad[i] for i in (2, 3, 4, 5))
+        Md = M.detach().contiguous()
+        Rd = None if R is None else R.detach().contiguous()
+        mode = _STATE["fuse_linear"]
+        fuse = (mode == "always" and linear_supported(F_in, F_out)) or \
+               (mode == "auto" and linear_fusion_pays(F_in, F_out))
+        if fuse and variant in ("auto", "pull", "fused"):
+            plan = cached_plan(N, csrptr_t, indices_t)
+            T = torch.empty_like(node_feat) if need_t else None
+            out = plan.aggregate_linear(csrptr_t, indices_t, node_feat.detach(), Md, degE, degV, W, variant=variant,
+                                        residual=Rd, ca=ca, cb=cbf, relu=relu, t_out=T)
+        else:
+            T = _SumAggrLinear._aggr(csrptr_t, indices_t, node_feat.detach(), degE, degV, W) * ca
+            if Rd is not None:
+                T = T + Rd * cbf
+            out = T @ Md.t()
+            if relu:
+                out = torch.relu(out)
+        ctx.graph = (csrptr_t, indices_t)
+        ctx.scales = (degE, degV, W)
+        ctx.consts = (ca, cbf, relu)
+        ctx.save_for_backward(M, R if R is not None else M.new_empty(0), T if T is not None else M.new_empty(0), out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        M, R, T, out = ctx.saved_tensors
+        ca, cbf, relu = ctx.consts
+        degE, degV, W = ctx.scales
+        csrptr_t, indices_t = ctx.graph
+        dP = grad_out.contiguous()
+        if relu:
+            dP = dP * (out > 0)
+        dT = dP @ M
+        gM = dP.t() @ T if ctx.needs_input_grad[3] else None
+        gx = None
+        if ctx.needs_input_grad[2]:
+            g_in = dT * ca
+            if _STATE["backward"] == "reference" or degV is None:
+                gx = _SumAggrLinear._aggr(csrptr_t, indices_t, g_in, degE, degV, W)
+            else:
+                gx = _SumAggrLinear._aggr(csrptr_t, indices_t, g_in * degV.reshape(-1, 1), degE, None, W)
+        gR = dT * cbf if (R.numel() and ctx.needs_input_grad[4]) else None
+        gcb = (dT * R).sum() if (R.numel() and ctx.needs_input_grad[5]) else None
+        return None, None, gx, gM, gR, gcb, None, None, None, None, None
+
+
+def aggr_res_linear(csrptr_t, indices_t, node_feat, M, residual=None, ca=1.0, cb=0.0, degE=None, degV=None, W=None,
+                    relu=False):
+    """act((ca * Aggr(node_feat) + cb * residual) . M^T) in one pass where the widths allow
+    (include/hg_aggr.h, hg_aggr_linear_res_f32).  cb may be a tensor (its gradient is returned)."""
+    cb_t = cb if isinstance(cb, torch.Tensor) else torch.tensor(float(cb), device=node_feat.device)
+    return _AggrResLinear.apply(csrptr_t, indices_t, node_feat, M, residual, cb_t, degE, degV, W, float(ca), bool(relu))
 
 
 def hgnnaggr_linear(csrptr_t, indices_t, node_feat, weight, degE=None, degV=None, W=None):

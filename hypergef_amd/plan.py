@@ -150,9 +150,12 @@ class Plan:
         return Y
 
     def aggregate_linear(self, csrptr_t, colind_t, X, weight, degE=None, degV=None, W=None,
-                         variant="auto", out=None, workspace=None, packed=None):
+                         variant="auto", out=None, workspace=None, packed=None, residual=None, ca=1.0,
+                         cb=0.0, relu=False, t_out=None):
         """Y[N, F_out] = Aggr(X) . weight^T in one pass (hg_aggr_linear_f32); weight = nn.Linear.weight,
         [F_out, F_in]; packed = pack_linear(weight) if the caller keeps it across calls.
+        With residual / ca / cb / relu / t_out: Y = act((ca * Aggr(X) + cb * residual) . weight^T) and
+        t_out receives the bracket (hg_aggr_linear_res_f32: one UniGCNII / UniGIN layer per pass).
         Raises HgError(unsupported) for widths the MFMA epilogue does not take."""
         _check_feat(X, "node_feat")
         _check_feat(weight, "weight", device=X.device)
@@ -180,10 +183,15 @@ class Plan:
             workspace = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=X.device)
         nbytes = workspace.numel() * workspace.element_size()
         with torch.cuda.device(X.device):
-            _lib.check(_lib.lib().hg_aggr_linear_f32(
+            for name, t in (("residual", residual), ("t_out", t_out)):
+                if t is not None:
+                    _check_feat(t, name, device=X.device)
+                    if tuple(t.shape) != (self.N, F_in):
+                        raise ValueError("%s must be [N, F_in]" % name)
+            _lib.check(_lib.lib().hg_aggr_linear_res_f32(
                 self._h, F_in, F_out, _ptr(csrptr_t), _ptr(colind_t), _ptr(X), _ptr(degE), _ptr(degV),
-                _ptr(W), _ptr(weight), _ptr(Y), _ptr(workspace), nbytes, _lib.VARIANTS[variant],
-                _stream_handle(X.device)))
+                _ptr(W), _ptr(weight), _ptr(residual), float(ca), float(cb), 1 if relu else 0, _ptr(t_out),
+                _ptr(Y), _ptr(workspace), nbytes, _lib.VARIANTS[variant], _stream_handle(X.device)))
         return Y
 
     def _bind_scales(self, F, degE, degV, W, device):

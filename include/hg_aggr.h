@@ -228,6 +228,23 @@ HG_API int hg_aggr_fused_f32(const hg_plan *plan, int32_t F,
 HG_API int hg_linear_pack_f32(int32_t F_out, int32_t F_in, const float *Wlin, float *wfrag,
                               hg_stream_t stream);
 HG_API size_t hg_aggr_linear_workspace_bytes(const hg_plan *plan, int32_t F_in);
+/* The same pass with a whole UniGNN layer folded in.  For every vertex v
+ *     t     = ca * Aggr(X)[v] + cb * R[v]          (R NULL: t = ca * Aggr(X)[v])
+ *     T_out[v] = t                                  (if T_out != NULL; the backward pass needs it)
+ *     Y[v]  = act(t * Wlin^T),  act = relu if relu != 0 else identity
+ * R and T_out are [N, F_in] row-major, 16-byte aligned.  This is one HyperGsysUniGCNII layer
+ * (model/ugsys/unigcnii.py:19-21 with the relu of model/gnn.py:199): Xi = (1-alpha) Xv + alpha X0,
+ * out = (1-beta) Xi + beta W(Xi) = Xi * ((1-beta) I + beta W)^T -- pack that matrix as wfrag --
+ * and one HyperGsysUinGINConv layer (unigin.py:20-22): (1+eps) W(X) + Aggr(W(X)) =
+ * ((1+eps) X + Aggr(X)) * W^T.  Arithmetic: the two products and the sum of t are separate fp32
+ * operations in that order, then the MFMA fma chain; the value equals the reference's layer up
+ * to fp32 rounding order. */
+HG_API int hg_aggr_linear_res_f32(const hg_plan *plan, int32_t F_in, int32_t F_out,
+                                  const int32_t *csrptr_t, const int32_t *colind_t, const float *X,
+                                  const float *degE, const float *degV, const float *W,
+                                  const float *wfrag, const float *R, float ca, float cb, int32_t relu,
+                                  float *T_out, float *Y, void *workspace, size_t workspace_bytes,
+                                  int32_t variant, hg_stream_t stream);
 /* The projection alone, Y[nrows, F_out] = T[nrows, F_in] * Wlin^T, on the same MFMA kernel the
  * fallback path of hg_aggr_linear_f32 uses (same width limits, same packed wfrag). */
 HG_API int hg_linear_rows_f32(int64_t nrows, int32_t F_in, int32_t F_out, const float *T,

@@ -661,3 +661,67 @@ def test_host_side_cost_per_call_stays_below_the_kernel(hg):
     wall = time.perf_counter() - t0
     dev_s = e0.elapsed_time(e1) * 1e-3
     assert wall < 1.5 * dev_s + 2e-3, "wall %.3f ms vs device %.3f ms for %d calls" % (wall * 1e3, dev_s * 1e3, n)
+
+
+@pytest.mark.parametrize("shape", ["cora", "pubmed", "powerlaw"])
+def test_layer_epilogue_residual_relu(hg, oracle, shape):
+    """hg_aggr_linear_res_f32: Y = relu((ca * Aggr(X) + cb * R) . M^T), T_out = the bracket -- fused
+    panels, pull fallback and hub fallback -- against the same formula on the oracle's aggregation."""
+    from hypergef_amd.plan import Plan
+    inc = _make(shape)
+    ptr, ind = _dev(inc.csrptr), _dev(inc.colind)
+    plan = Plan.from_tensors(inc.N, ptr, ind)
+    rng = np.random.default_rng(21)
+    for F_in, F_out in ((64, 64), (32, 48), (128, 128)):
+        X, degE, degV, W, H_ptr, H_ind = _inputs(inc, F_in, oracle, seed=22, normal=True)
+        if shape == "powerlaw":
+            degE = np.where(np.isinf(degE), 0, degE).astype(np.float32)
+        R = rng.standard_normal((inc.N, F_in)).astype(np.float32)
+        Ml = (rng.standard_normal((F_out, F_in)) / np.sqrt(F_in)).astype(np.float32)
+        ca, cb = 0.9, 0.1
+        agg = oracle.hgnn_check(inc.N, inc.M, F_in, H_ptr, H_ind, inc.csrptr, inc.colind, X, degE, degV, None)
+        T_ref = (agg * np.float32(ca) + R * np.float32(cb)).astype(np.float32)
+        Y_lin = (T_ref.astype(np.float64) @ Ml.T.astype(np.float64)).astype(np.float32)
+        for variant in ("auto", "pull", "fused"):
+            for relu in (False, True):
+                T = torch.full((inc.N, F_in), float("nan"), device=DEV)
+                Y = plan.aggregate_linear(ptr, ind, _dev(X), _dev(Ml), _dev(degE.ravel()), _dev(degV.ravel()), None,
+                                          variant=variant, residual=_dev(R), ca=ca, cb=cb, relu=relu, t_out=T)
+                _assert_close(T, T_ref) if shape != "powerlaw" else _assert_close_linear(T, T_ref)
+                _assert_close_linear(Y, np.maximum(Y_lin, 0) if relu else Y_lin)
+
+
+def test_unignn_layers_fused_match_reference_formulas(hg, oracle):
+    """HyperGsysUniGCNII / HyperGsysUinGINConv with the one-pass epilogue against their own two-step
+    formulas (model/ugsys/unigcnii.py:19-21, unigin.py:20-22): outputs and every gradient."""
+    from hypergef_amd import models, ops
+    inc = synth.cora_shape()
+    hyperg = hg.HyperGraph.from_incidence(inc, DEV, ngs=1 << 30)
+    Fh = 64
+    torch.manual_seed(5)
+    for kind in ("gcnii", "gin"):
+        layer = (models.HyperGsysUniGCNII(hyperg, Fh, Fh) if kind == "gcnii"
+                 else models.HyperGsysUinGINConv(hyperg, Fh, Fh, "sum")).to(DEV)
+        if kind == "gin":
+            layer.eps.data.fill_(0.25)
+        X = torch.randn(inc.N, Fh, device=DEV, requires_grad=True)
+        X0 = torch.randn(inc.N, Fh, device=DEV, requires_grad=True)
+        G = torch.randn(inc.N, Fh, device=DEV)
+        results = []
+        for mode in ("auto", "never"):
+            ops.set_fuse_linear(mode)
+            try:
+                for t in (X, X0):
+                    t.grad = None
+                layer.zero_grad()
+                out = layer(X, X0, 0.1, 0.4, relu=True) if kind == "gcnii" else layer(X)
+                out.backward(G)
+                grads = [X.grad.clone(), layer.W.weight.grad.clone()]
+                grads.append(X0.grad.clone() if kind == "gcnii" else layer.eps.grad.clone())
+                results.append((out.detach().clone(), grads))
+            finally:
+                ops.set_fuse_linear("auto")
+        (o1, g1), (o2, g2) = results
+        assert torch.allclose(o1, o2, rtol=1e-4, atol=1e-5)
+        for a, b in zip(g1, g2):
+            assert torch.allclose(a, b, rtol=1e-3, atol=1e-4 * max(1.0, float(b.abs().max()))), kind
