@@ -7,4 +7,7 @@ done; done
 for b in hgsys torch; do python tools/hgsys.py --model HGNN --backend $b --dname pubmed --nhid 128 --epochs 100 --output $out > /dev/null 2>&1; done
 for b in hgsys torch; do python tools/hgsys.py --model HGNN --backend $b --dname cora --replicas 256 --epochs 30 --output $out > /dev/null 2>&1; done
 for b in hgsys torch; do python tools/hgsys.py --model HGNN --backend $b --dname cora --replicas 256 --nhid 64 --nlayer 4 --nfeat 64 --epochs 30 --output $out > /dev/null 2>&1; done
+for m in UniGCNII UniGIN; do for b in hgsys torch; do
+  python tools/hgsys.py --model $m --backend $b --dname cora --replicas 256 --nhid 64 --nlayer 8 --nfeat 64 --epochs 20 --output $out > /dev/null 2>&1
+done; done
 cat $out
