@@ -117,6 +117,15 @@ class _SumAggr(torch.autograd.Function):
         return (None,) * 6 + (g, None, None, None)
 
 
+def _rows_times(A, B):
+    """A . B for tall-skinny A [N, K], B [K, F]: the library's MFMA rows kernel where it takes the
+    widths (1.4-1.5x rocBLAS at K <= 64), torch otherwise.  Backward-pass GEMMs use it."""
+    K, F = B.shape
+    if _STATE["fuse_linear"] != "never" and A.is_cuda and linear_supported(K, F) and A.shape[0] >= 4096:
+        return linear_rows(A.contiguous(), B.t().contiguous())
+    return A @ B
+
+
 class _SumAggrLinear(torch.autograd.Function):
     """Aggr(X . Wlin^T) as one node: the layer's bias-free nn.Linear followed by the sum
     aggregation (HyperGsysHGNN.forward, model/ugsys/hgnn.py:22-23; HyperGsysUinGINConv.forward,
@@ -171,7 +180,7 @@ class _SumAggrLinear(torch.autograd.Function):
             dZ = _SumAggrLinear._aggr(csrptr_t, indices_t, grad_out, degE, degV, W)
         else:
             dZ = _SumAggrLinear._aggr(csrptr_t, indices_t, grad_out * degV.reshape(-1, 1), degE, None, W)
-        gx = dZ @ weight if ctx.needs_input_grad[2] else None
+        gx = _rows_times(dZ, weight) if ctx.needs_input_grad[2] else None
         gw = dZ.t() @ node_feat if ctx.needs_input_grad[3] else None
         return None, None, gx, gw, None, None, None
 
@@ -228,7 +237,7 @@ class _AggrResLinear(torch.autograd.Function):
         dP = grad_out.contiguous()
         if relu:
             dP = dP * (out > 0)
-        dT = dP @ M
+        dT = _rows_times(dP, M)
         gM = dP.t() @ T if ctx.needs_input_grad[3] else None
         gx = None
         if ctx.needs_input_grad[2]:
