@@ -770,6 +770,30 @@ int hg_linear_rows_f32(int64_t nrows, int32_t F_in, int32_t F_out, const float *
   return HG_OK;
 }
 
+size_t hg_linear_wgrad_workspace_bytes(int64_t nrows, int32_t F_a, int32_t F_b) {
+  if (nrows < 0 || F_a <= 0 || F_b <= 0) return 0;
+  return (size_t)(hg::wgrad_parts(nrows) + 32) * F_a * F_b * sizeof(float);  // + second-level partials
+}
+
+int hg_linear_wgrad_f32(int64_t nrows, int32_t F_a, int32_t F_b, const float *A, const float *B, float *C,
+                        void *workspace, size_t workspace_bytes, hg_stream_t stream) {
+  if (nrows < 0 || !C || (nrows > 0 && (!A || !B))) {
+    hg::set_error("hg_linear_wgrad_f32: bad argument");
+    return HG_ERR_INVALID;
+  }
+  if (F_a <= 0 || F_b <= 0 || (F_a % 16) || (F_b % 16) || (F_a / 16) * (F_b / 16) > 16) {
+    hg::set_error("hg_linear_wgrad_f32: need F_a, F_b multiples of 16 with F_a * F_b <= 4096");
+    return HG_ERR_UNSUPPORTED;
+  }
+  if (!workspace || workspace_bytes < hg_linear_wgrad_workspace_bytes(nrows, F_a, F_b)) {
+    hg::set_error("hg_linear_wgrad_f32: workspace smaller than hg_linear_wgrad_workspace_bytes");
+    return HG_ERR_WORKSPACE;
+  }
+  hipError_t e = hg::launch_wgrad(nrows, F_a, F_b, A, B, C, static_cast<float *>(workspace), static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return hip_fail("wgrad launch", e);
+  return HG_OK;
+}
+
 size_t hg_aggr_linear_workspace_bytes(const hg_plan *plan, int32_t F_in) {
   if (!plan || F_in <= 0) return 0;
   return hg_plan_workspace_bytes(plan, F_in) + round256((size_t)plan->N * F_in * sizeof(float));

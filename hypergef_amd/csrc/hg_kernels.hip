@@ -520,6 +520,83 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KSTEPS >= 3
                          threadIdx.x, bv, a.epi.relu);
 }
 
+// ---- weight gradient of the layer's linear: C[Fa, Fb] = A^T B over N rows --------------------
+// dWlin = dP^T T (and HGNN's dZ^T X): a product whose contraction runs over the N vertices.  rocBLAS
+// spends 1.24 ms on [64 x 693 k] x [693 k x 64] (47 % of a UniGCNII training epoch) where reading
+// both operands once takes 0.07 ms.  Here every wave streams its share of the rows straight into
+// MFMA operands -- lane l holds A[n + (l>>4)][16 i + (l&15)] and B[n + (l>>4)][16 j + (l&15)], the
+// 16x16x4 layout with k = 4 consecutive rows -- so each element is loaded exactly once, and keeps
+// all TA x TB output tiles in accumulators; waves are reduced through LDS in wave order,
+// workgroups through one partial matrix each and a second kernel (fixed order: deterministic).
+template <int TA, int TB>
+__global__ __launch_bounds__(256) void wgrad_kernel(const float *A, const float *B, float *partial, int64_t N,
+                                                    int64_t rows_per_wg) {
+  constexpr int FA = TA * 16, FB = TB * 16;
+  __shared__ float red[FA * FB];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int kk = lane >> 4, c = lane & 15;
+  const int64_t wg0 = (int64_t)blockIdx.x * rows_per_wg;
+  const int64_t wg1 = min(N, wg0 + rows_per_wg);
+  const int64_t per_wave = (rows_per_wg / 4 + 3) & ~(int64_t)3;  // multiple of 4 rows
+  const int64_t r0 = min(wg1, wg0 + wave * per_wave), r1 = min(wg1, r0 + per_wave);
+  hg_f4 acc[TA][TB];
+#pragma unroll
+  for (int i = 0; i < TA; i++)
+#pragma unroll
+    for (int j = 0; j < TB; j++) acc[i][j] = hg_f4{0.f, 0.f, 0.f, 0.f};
+  float a0[TA], b0[TB], a1[TA], b1[TB];
+  auto load = [&](int64_t n, float (&a)[TA], float (&b)[TB]) {
+    const int64_t row = n + kk;
+    const bool ok = row < r1;
+#pragma unroll
+    for (int i = 0; i < TA; i++) a[i] = ok ? A[row * FA + i * 16 + c] : 0.f;
+#pragma unroll
+    for (int j = 0; j < TB; j++) b[j] = ok ? B[row * FB + j * 16 + c] : 0.f;
+  };
+  if (r0 < r1) load(r0, a0, b0);
+  for (int64_t n = r0; n < r1; n += 4) {
+    if (n + 4 < r1) load(n + 4, a1, b1);  // next four rows in flight behind this step's MFMAs
+#pragma unroll
+    for (int i = 0; i < TA; i++)
+#pragma unroll
+      for (int j = 0; j < TB; j++)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < TA; i++) a0[i] = a1[i];
+#pragma unroll
+    for (int j = 0; j < TB; j++) b0[j] = b1[j];
+  }
+  // D layout: register q of tile (i, j) is C[16 i + 4 (lane >> 4) + q][16 j + (lane & 15)]
+  for (int w = 0; w < 4; w++) {
+    if (wave == w) {
+#pragma unroll
+      for (int i = 0; i < TA; i++)
+#pragma unroll
+        for (int j = 0; j < TB; j++)
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            float *d = red + (i * 16 + 4 * kk + q) * FB + j * 16 + c;
+            *d = w == 0 ? acc[i][j][q] : *d + acc[i][j][q];
+          }
+    }
+    __syncthreads();
+  }
+  float *out = partial + (int64_t)blockIdx.x * FA * FB;
+  for (int i = threadIdx.x; i < FA * FB; i += 256) out[i] = red[i];
+}
+
+// out[c * n + i] = sum over parts p = c, c + nchunks, c + 2 nchunks, ... of partial[p * n + i]
+// (blockIdx.y = c).  Run twice -- nparts -> 32 chunks -> 1 -- so that the sum over a thousand
+// partial matrices is spread over 512 workgroups instead of sixteen.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *partial, int nparts, int n, float *out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int c = blockIdx.y, nchunks = gridDim.y;
+  float s = 0.f;
+  for (int p = c; p < nparts; p += nchunks) s += partial[(int64_t)p * n + i];
+  out[(int64_t)c * n + i] = s;
+}
+
 // Packed form of the fused panel kernel.  The plan hands every panel over as ONE
 // contiguous int32 record (hg_fused.cpp, pack_records): a single coalesced copy
 // stages it, and hop 1 is a wave-uniform loop over a [step][group] entry stream in
@@ -954,6 +1031,36 @@ hipError_t launch_linear_pack(int32_t F_out, int32_t F_in, const float *Wlin, fl
   const int64_t n = (int64_t)F_out * F_in;
   hipLaunchKernelGGL(linear_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, F_out, F_in,
                      Wlin, wfrag);
+  return hipGetLastError();
+}
+
+int wgrad_parts(int64_t nrows) { return (int)std::max<int64_t>(1, std::min<int64_t>(1024, (nrows + 63) / 64)); }
+
+hipError_t launch_wgrad(int64_t nrows, int32_t Fa, int32_t Fb, const float *A, const float *B, float *C,
+                        float *partial, hipStream_t stream) {
+  if ((Fa & 15) || (Fb & 15) || Fa <= 0 || Fb <= 0 || (Fa / 16) * (Fb / 16) > 16) return hipErrorInvalidValue;
+  const int nparts = wgrad_parts(nrows);
+  int64_t rows_per_wg = (nrows + nparts - 1) / nparts;
+  rows_per_wg = (rows_per_wg + 15) & ~(int64_t)15;
+#define HG_WG(TA_, TB_)                                                                                          \
+  if (Fa == 16 * TA_ && Fb == 16 * TB_) {                                                                        \
+    hipLaunchKernelGGL((wgrad_kernel<TA_, TB_>), dim3(nparts), dim3(256), 0, stream, A, B, partial, nrows, rows_per_wg); \
+  } else
+  HG_WG(1, 1) HG_WG(1, 2) HG_WG(2, 1) HG_WG(2, 2) HG_WG(1, 4) HG_WG(4, 1) HG_WG(2, 4) HG_WG(4, 2) HG_WG(4, 4)
+  HG_WG(1, 8) HG_WG(8, 1) HG_WG(2, 8) HG_WG(8, 2) HG_WG(1, 3) HG_WG(3, 1) HG_WG(3, 3) HG_WG(3, 4) HG_WG(4, 3)
+  HG_WG(2, 3) HG_WG(3, 2) { return hipErrorInvalidValue; }
+#undef HG_WG
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  const int n = Fa * Fb;
+  const int mid = nparts > 64 ? 32 : 1;  // second-level partials live behind the first-level ones
+  if (mid > 1) {
+    float *p2 = partial + (int64_t)nparts * n;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 255) / 256, mid), dim3(256), 0, stream, partial, nparts, n, p2);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 255) / 256, 1), dim3(256), 0, stream, p2, mid, n, C);
+  } else {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 255) / 256, 1), dim3(256), 0, stream, partial, nparts, n, C);
+  }
   return hipGetLastError();
 }
 

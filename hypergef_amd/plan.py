@@ -268,6 +268,27 @@ def linear_rows(X, weight, packed=None, out=None):
     return Y
 
 
+def wgrad_supported(F_a, F_b):
+    return F_a > 0 and F_b > 0 and F_a % 16 == 0 and F_b % 16 == 0 and (F_a // 16) * (F_b // 16) <= 16
+
+
+def linear_wgrad(A, B):
+    """A^T . B for A [N, F_a], B [N, F_b] (the linear's weight gradient, hg_linear_wgrad_f32)."""
+    _check_feat(A, "A")
+    _check_feat(B, "B", device=A.device)
+    if A.dim() != 2 or B.dim() != 2 or A.shape[0] != B.shape[0]:
+        raise ValueError("A and B must be [N, F_a] and [N, F_b]")
+    N, F_a = A.shape
+    F_b = B.shape[1]
+    nbytes = int(_lib.lib().hg_linear_wgrad_workspace_bytes(N, F_a, F_b))
+    ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=A.device)
+    C = torch.empty((F_a, F_b), dtype=torch.float32, device=A.device)
+    with torch.cuda.device(A.device):
+        _lib.check(_lib.lib().hg_linear_wgrad_f32(N, F_a, F_b, _ptr(A), _ptr(B), _ptr(C), _ptr(ws), nbytes,
+                                                  _stream_handle(A.device)))
+    return C
+
+
 class _NullCtx:
     def __enter__(self):
         return self

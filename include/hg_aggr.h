@@ -245,6 +245,14 @@ HG_API int hg_aggr_linear_res_f32(const hg_plan *plan, int32_t F_in, int32_t F_o
                                   const float *wfrag, const float *R, float ca, float cb, int32_t relu,
                                   float *T_out, float *Y, void *workspace, size_t workspace_bytes,
                                   int32_t variant, hg_stream_t stream);
+/* The linear's weight gradient, C[F_a, F_b] = A^T B with A [nrows, F_a], B [nrows, F_b] row-major:
+ * dWlin = dY^T T in the backward pass of the layers above (the contraction runs over the vertices).
+ * Every element of A and B is read once, straight into fp32 MFMA operands; workgroups are reduced
+ * in a fixed order (deterministic).  F_a, F_b multiples of 16 with F_a * F_b <= 4096 (else
+ * HG_ERR_UNSUPPORTED: use a BLAS); workspace = hg_linear_wgrad_workspace_bytes. */
+HG_API size_t hg_linear_wgrad_workspace_bytes(int64_t nrows, int32_t F_a, int32_t F_b);
+HG_API int hg_linear_wgrad_f32(int64_t nrows, int32_t F_a, int32_t F_b, const float *A, const float *B,
+                               float *C, void *workspace, size_t workspace_bytes, hg_stream_t stream);
 /* The projection alone, Y[nrows, F_out] = T[nrows, F_in] * Wlin^T, on the same MFMA kernel the
  * fallback path of hg_aggr_linear_f32 uses (same width limits, same packed wfrag). */
 HG_API int hg_linear_rows_f32(int64_t nrows, int32_t F_in, int32_t F_out, const float *T,

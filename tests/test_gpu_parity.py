@@ -725,3 +725,24 @@ def test_unignn_layers_fused_match_reference_formulas(hg, oracle):
         assert torch.allclose(o1, o2, rtol=1e-4, atol=1e-5)
         for a, b in zip(g1, g2):
             assert torch.allclose(a, b, rtol=1e-3, atol=1e-4 * max(1.0, float(b.abs().max()))), kind
+
+
+def test_linear_wgrad_kernel(hg):
+    """C = A^T B over the rows (hg_linear_wgrad_f32) against a float64 product."""
+    from hypergef_amd.plan import linear_wgrad, wgrad_supported
+    from hypergef_amd import _lib
+    rng = np.random.default_rng(4)
+    for N, Fa, Fb in ((1, 16, 16), (63, 64, 64), (4097, 64, 64), (100000, 32, 128), (70001, 128, 32), (5000, 48, 48),
+                      (333, 64, 16)):
+        assert wgrad_supported(Fa, Fb)
+        A = rng.standard_normal((N, Fa)).astype(np.float32)
+        B = rng.standard_normal((N, Fb)).astype(np.float32)
+        ref = A.astype(np.float64).T @ B.astype(np.float64)
+        C = linear_wgrad(_dev(A), _dev(B)).cpu().numpy()
+        scale = np.sqrt(N)  # size of a sum of N unit-variance products
+        assert np.abs(C - ref).max() <= 2e-5 * max(1.0, scale * 4), (N, Fa, Fb, np.abs(C - ref).max())
+        C2 = linear_wgrad(_dev(A), _dev(B)).cpu().numpy()
+        assert np.array_equal(C, C2)  # fixed reduction order
+    assert not wgrad_supported(128, 128) and not wgrad_supported(20, 16)
+    with pytest.raises(_lib.HgError):
+        linear_wgrad(torch.zeros(10, 128, device=DEV), torch.zeros(10, 128, device=DEV))
