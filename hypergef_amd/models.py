@@ -26,7 +26,7 @@ from .ops import HGNNAggr, HGNNAggrLinear, UniGNNConv, UniGNNConvdeg
 class HyperGsysHGNN(nn.Module):
     def __init__(self, hyperg, in_channels, out_channels, first_aggr, heads=1):
         super().__init__()
-        self.W = nn.Linear(in_channels, heads * out_channels, bias=False)
+        self.W = ops.Linear(in_channels, heads * out_channels, bias=False)
         self.Wdiag = torch.ones(hyperg.degE.shape[0]).to(hyperg.device)
         self.heads, self.in_channels, self.out_channels = heads, in_channels, out_channels
         self.hyperg, self.degE, self.degV = hyperg, hyperg.degE, hyperg.degV
@@ -43,7 +43,7 @@ class HyperGsysHGNN(nn.Module):
 class HyperGsysUinGINConv(nn.Module):
     def __init__(self, hyperg, in_channels, out_channels, first_aggr, heads=1):
         super().__init__()
-        self.W = nn.Linear(in_channels, heads * out_channels, bias=False)
+        self.W = ops.Linear(in_channels, heads * out_channels, bias=False)
         self.heads, self.in_channels, self.out_channels = heads, in_channels, out_channels
         self.hyperg, self.degE, self.degV = hyperg, hyperg.degE, hyperg.degV
         self.eps = nn.parameter.Parameter(torch.FloatTensor([0]))
@@ -61,7 +61,7 @@ class HyperGsysUinGINConv(nn.Module):
 class HyperGsysUniGCNII(nn.Module):
     def __init__(self, hyperg, in_channels, out_channels, heads=1):
         super().__init__()
-        self.W = nn.Linear(in_channels, out_channels, bias=False)
+        self.W = ops.Linear(in_channels, out_channels, bias=False)
         self.heads, self.in_channels, self.out_channels = heads, in_channels, out_channels
         self.hyperg, self.degE, self.degV = hyperg, hyperg.degE, hyperg.degV
 
@@ -71,7 +71,9 @@ class HyperGsysUniGCNII(nn.Module):
                 and self.W.weight.shape[0] == F:
             # Xi = (1 - alpha) Xv + alpha X0;  (1 - beta) Xi + beta W(Xi) = Xi . ((1 - beta) I + beta W)^T:
             # aggregation, both mixes, the projection and the model's relu in one pass
-            M = (1 - beta) * torch.eye(F, device=X.device, dtype=X.dtype) + beta * self.W.weight
+            if getattr(self, "_eye", None) is None or self._eye.device != X.device:
+                self._eye = torch.eye(F, device=X.device, dtype=X.dtype)
+            M = torch.lerp(self._eye, self.W.weight, float(beta))  # (1 - beta) I + beta W, one kernel
             return ops.aggr_res_linear(self.hyperg.H_T_csrptr, self.hyperg.H_T_colind, X, M, residual=X0,
                                        ca=1 - alpha, cb=alpha, degE=self.degE, degV=self.degV, relu=relu)
         Xv = UniGNNConvdeg(self.hyperg, X, self.degE, self.degV)
@@ -178,13 +180,14 @@ class UniGCNII(nn.Module):
         self.act = {"relu": nn.ReLU(), "prelu": nn.PReLU()}[args.activation]
         self.input_drop = nn.Dropout(args.input_drop)
         self.dropout = nn.Dropout(args.dropout)
-        self.convs = nn.ModuleList([nn.Linear(nfeat, nhid)])
+        lin = nn.Linear if getattr(args, "backend", "hgsys") == "torch" else ops.Linear  # same module, own wgrad kernel
+        self.convs = nn.ModuleList([lin(nfeat, nhid)])
         if getattr(args, "backend", "hgsys") == "torch":
             tg = _TorchGraph(hyperg, getattr(args, "device", hyperg.device))
             self.convs.extend(TorchGCNIIConv(tg, nhid, nhid) for _ in range(nlayer))
         else:
             self.convs.extend(HyperGsysUniGCNII(hyperg, nhid, nhid) for _ in range(nlayer))
-        self.convs.append(nn.Linear(nhid, nclass))
+        self.convs.append(lin(nhid, nclass))
         self.reg_params = list(self.convs[1:-1].parameters())
         self.non_reg_params = list(self.convs[0:1].parameters()) + list(self.convs[-1:].parameters())
 

@@ -126,13 +126,53 @@ def _rows_times(A, B):
     return A @ B
 
 
+def _pad16(t):
+    pad = (-t.shape[1]) % 16
+    return t if pad == 0 else torch.nn.functional.pad(t, (0, pad))
+
+
 def _wgrad(A, B):
     """A^T . B over the vertices (the linear's weight gradient): the library's streaming MFMA kernel
     where it takes the widths -- rocBLAS needs 1.2 ms for [64 x 693 k] x [693 k x 64], 17x the time of
     reading the operands -- torch otherwise."""
-    if _STATE["fuse_linear"] != "never" and A.is_cuda and wgrad_supported(A.shape[1], B.shape[1]) and A.shape[0] >= 4096:
-        return linear_wgrad(A.contiguous(), B.contiguous())
+    if _STATE["fuse_linear"] != "never" and A.is_cuda and A.shape[0] >= 4096:
+        Fa, Fb = A.shape[1], B.shape[1]
+        if wgrad_supported(Fa, Fb):
+            return linear_wgrad(A.contiguous(), B.contiguous())
+        Pa, Pb = Fa + (-Fa) % 16, Fb + (-Fb) % 16
+        if wgrad_supported(Pa, Pb):  # e.g. the class-count layer: pad to the next 16 columns, cut the result
+            return linear_wgrad(_pad16(A).contiguous(), _pad16(B).contiguous())[:Fa, :Fb]
     return A.t() @ B
+
+
+class _LinearFn(torch.autograd.Function):
+    """torch.nn.functional.linear with this library's weight-gradient kernel in the backward
+    (x^T-style contraction over the vertices; see _wgrad)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, weight = ctx.saved_tensors
+        grad = grad.contiguous()
+        gx = _rows_times(grad, weight) if ctx.needs_input_grad[0] else None
+        gw = _wgrad(grad, x) if ctx.needs_input_grad[1] else None
+        gb = grad.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb
+
+
+class Linear(torch.nn.Linear):
+    """Drop-in nn.Linear (same parameters, same state_dict) for the [N, F] activations of these
+    models: identical forward, weight gradient on hg_linear_wgrad_f32."""
+
+    def forward(self, x):
+        if x.dim() == 2 and x.is_cuda and x.dtype == torch.float32:
+            return _LinearFn.apply(x, self.weight, self.bias)
+        return super().forward(x)
 
 
 class _SumAggrLinear(torch.autograd.Function):

@@ -746,3 +746,23 @@ def test_linear_wgrad_kernel(hg):
     assert not wgrad_supported(128, 128) and not wgrad_supported(20, 16)
     with pytest.raises(_lib.HgError):
         linear_wgrad(torch.zeros(10, 128, device=DEV), torch.zeros(10, 128, device=DEV))
+
+
+def test_own_linear_module_matches_nn_linear(hg):
+    from hypergef_amd import ops
+    torch.manual_seed(9)
+    for n_in, n_out, bias in ((64, 64, True), (64, 7, True), (20, 32, False)):
+        ref = torch.nn.Linear(n_in, n_out, bias=bias).to(DEV)
+        own = ops.Linear(n_in, n_out, bias=bias).to(DEV)
+        own.load_state_dict(ref.state_dict())
+        x1 = torch.randn(6000, n_in, device=DEV, requires_grad=True)
+        x2 = x1.detach().clone().requires_grad_()
+        g = torch.randn(6000, n_out, device=DEV)
+        y1, y2 = ref(x1), own(x2)
+        assert torch.equal(y1, y2)
+        y1.backward(g)
+        y2.backward(g)
+        assert torch.allclose(x1.grad, x2.grad, rtol=1e-4, atol=1e-5)
+        assert torch.allclose(ref.weight.grad, own.weight.grad, rtol=1e-4, atol=2e-3)
+        if bias:
+            assert torch.allclose(ref.bias.grad, own.bias.grad, rtol=1e-4, atol=1e-3)
