@@ -285,7 +285,7 @@ class _AggrResLinear(torch.autograd.Function):
         csrptr_t, indices_t = ctx.graph
         dP = grad_out.contiguous()
         if relu:
-            dP = dP * (out > 0)
+            dP = torch.ops.aten.threshold_backward(dP, out, 0.0)  # relu's own backward: one vectorised kernel
         dT = _rows_times(dP, M)
         gM = _wgrad(dP, T) if ctx.needs_input_grad[3] else None
         gx = None
