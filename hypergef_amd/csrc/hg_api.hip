@@ -772,7 +772,8 @@ int hg_linear_rows_f32(int64_t nrows, int32_t F_in, int32_t F_out, const float *
 
 size_t hg_linear_wgrad_workspace_bytes(int64_t nrows, int32_t F_a, int32_t F_b) {
   if (nrows < 0 || F_a <= 0 || F_b <= 0) return 0;
-  return (size_t)(hg::wgrad_parts(nrows) + 32) * F_a * F_b * sizeof(float);  // + second-level partials
+  if ((F_a % 16) || (F_b % 16)) return 0;
+  return (size_t)(hg::wgrad_parts(nrows, F_a, F_b) + 32) * F_a * F_b * sizeof(float);  // + second-level partials
 }
 
 int hg_linear_wgrad_f32(int64_t nrows, int32_t F_a, int32_t F_b, const float *A, const float *B, float *C,

@@ -86,7 +86,7 @@ hipError_t launch_gather(const GatherArgs &a, int nfix, int nfix_l1, const Fixup
 hipError_t launch_fused(const FusedArgs &a, bool vec4, hipStream_t stream);
 bool fused_linear_ok(const FusedArgs &a);  // can launch_fused run this call's linear epilogue?
 hipError_t launch_linear(const LinearArgs &a, hipStream_t stream);
-int wgrad_parts(int64_t nrows);
+int wgrad_parts(int64_t nrows, int32_t Fa, int32_t Fb);
 hipError_t launch_wgrad(int64_t nrows, int32_t Fa, int32_t Fb, const float *A, const float *B, float *C,
                         float *partial, hipStream_t stream);
 hipError_t launch_linear_pack(int32_t F_out, int32_t F_in, const float *Wlin, float *wfrag, hipStream_t stream);

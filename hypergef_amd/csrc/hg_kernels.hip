@@ -553,18 +553,26 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *A, const float 
 #pragma unroll
     for (int j = 0; j < TB; j++) b[j] = ok ? B[row * FB + j * 16 + c] : 0.f;
   };
+  float a2[TA], b2[TB];
   if (r0 < r1) load(r0, a0, b0);
+  if (r0 + 4 < r1) load(r0 + 4, a1, b1);
   for (int64_t n = r0; n < r1; n += 4) {
-    if (n + 4 < r1) load(n + 4, a1, b1);  // next four rows in flight behind this step's MFMAs
+    if (n + 8 < r1) load(n + 8, a2, b2);  // two steps (eight rows) in flight behind this step's MFMAs
 #pragma unroll
     for (int i = 0; i < TA; i++)
 #pragma unroll
       for (int j = 0; j < TB; j++)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
 #pragma unroll
-    for (int i = 0; i < TA; i++) a0[i] = a1[i];
+    for (int i = 0; i < TA; i++) {
+      a0[i] = a1[i];
+      a1[i] = a2[i];
+    }
 #pragma unroll
-    for (int j = 0; j < TB; j++) b0[j] = b1[j];
+    for (int j = 0; j < TB; j++) {
+      b0[j] = b1[j];
+      b1[j] = b2[j];
+    }
   }
   // D layout: register q of tile (i, j) is C[16 i + 4 (lane >> 4) + q][16 j + (lane & 15)]
   for (int w = 0; w < 4; w++) {
@@ -1034,12 +1042,18 @@ hipError_t launch_linear_pack(int32_t F_out, int32_t F_in, const float *Wlin, fl
   return hipGetLastError();
 }
 
-int wgrad_parts(int64_t nrows) { return (int)std::max<int64_t>(1, std::min<int64_t>(1024, (nrows + 63) / 64)); }
+// One resident round of workgroups: the accumulators (4 registers per output tile) decide how
+// many fit a CU -- 64 x 64: three, 32 x 32: eight.
+int wgrad_parts(int64_t nrows, int32_t Fa, int32_t Fb) {
+  const int tiles = (Fa / 16) * (Fb / 16);
+  const int64_t cap = tiles <= 4 ? 2048 : (tiles <= 8 ? 1024 : 768);
+  return (int)std::max<int64_t>(1, std::min<int64_t>(cap, (nrows + 63) / 64));
+}
 
 hipError_t launch_wgrad(int64_t nrows, int32_t Fa, int32_t Fb, const float *A, const float *B, float *C,
                         float *partial, hipStream_t stream) {
   if ((Fa & 15) || (Fb & 15) || Fa <= 0 || Fb <= 0 || (Fa / 16) * (Fb / 16) > 16) return hipErrorInvalidValue;
-  const int nparts = wgrad_parts(nrows);
+  const int nparts = wgrad_parts(nrows, Fa, Fb);
   int64_t rows_per_wg = (nrows + nparts - 1) / nparts;
   rows_per_wg = (rows_per_wg + 15) & ~(int64_t)15;
 #define HG_WG(TA_, TB_)                                                                                          \
