@@ -11,11 +11,23 @@ cora-shape hypergraphs (N=2708, M=1579, nnz=4859 each) as one block-diagonal
 incidence matrix, feat_len = 32, fp32.  The single-hypergraph latency (the
 number the reference's result.xlsx reports) is printed in `single_graph`.
 
-N > 1: one process per GPU (torchrun); the batch is sharded by hyperedge group
-= by hypergraph, K graphs per rank (weak scaling).  No vertex is shared between
-shards, so the data path has no collective; ranks meet in the barrier that
-brackets the timed region.  The dense all-reduce variant (every rank ends with
-all of Y) is timed separately and reported under `allreduce_dense`.
+The timed output is checked: after the timed region Y is compared with the CPU
+oracle on the same input (`parity`), and a mismatch makes the run fail -- the
+reference never times an unchecked variant either (TRY, hgnnAgg.cuh:1159-1169).
+
+`configs` (N = 1): the other BASELINE configurations measured the same way in
+the same run -- pubmed-shape x64 at F = 128 (config 3), the power-law
+|V|=1M |E|=4M hypergraph at F = 64 (config 4), and the weighted operator
+(degE, degV, W: HGNNConv itself) on the headline batch.
+
+N > 1: one process per GPU (torchrun).  Headline: the batch sharded by hyperedge
+group = by hypergraph, K graphs per rank (weak scaling); no vertex is shared
+between shards, so the data path has no collective and ranks meet in the barrier
+that brackets the timed region.  `sharded` (beside it): ONE hypergraph (config 4)
+cut into hyperedge groups across the ranks by hypergef_amd.dist.ShardedAggregator
+-- X replicated, each rank aggregates its hyperedges into a dense partial, one
+RCCL all-reduce (or reduce-scatter) of N*F*4 bytes over xGMI sums them: the
+configuration north_star names, strong scaling.
 
 One JSON line on stdout (rank 0).
 """
@@ -30,11 +42,14 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+U32 = 2.0 ** -24       # unit roundoff of fp32
 
 
-def b_alg(N, M, nnz, F, n_w):
-    """Algorithmic (compulsory) bytes of one fused aggregation, SURVEY.md 8(d)."""
-    return 4 * (2 * N * F + 2 * nnz + (M + 1) + (N + 1) + n_w * M + N)
+def b_alg(N, M, nnz, F, n_w, has_degV):
+    """Algorithmic (compulsory) bytes of one fused aggregation, SURVEY.md 8(d): X read and Y
+    written once, the incidence indices once per hop, both row-pointer arrays, the per-hyperedge
+    scale vectors (n_w of them) and degV -- each only when the operator reads it."""
+    return 4 * (2 * N * F + 2 * nnz + (M + 1) + (N + 1) + n_w * M + (N if has_degV else 0))
 
 
 def parse():
@@ -50,29 +65,41 @@ def parse():
     p.add_argument("--tile-bytes", type=int, default=0)
     p.add_argument("--weighted", action="store_true", help="hgnnaggr (degE, degV, W) instead of H H^T X")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--no-extras", action="store_true", help="skip single-graph / all-reduce extras")
+    p.add_argument("--no-parity", action="store_true", help="skip the oracle comparison of the timed output")
+    p.add_argument("--no-extras", action="store_true", help="skip device-copy / single-graph / sharded extras")
+    p.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs (N = 1)")
+    p.add_argument("--config-steps", type=int, default=50)
     p.add_argument("--short-max", type=int, default=0)
     p.add_argument("--panel-rows", type=int, default=0)
     p.add_argument("--panel-nnz", type=int, default=0)
     p.add_argument("--no-xcd-remap", action="store_true")
+    p.add_argument("--sharded-nodes", type=int, default=1_000_000, help="N > 1: the one hypergraph that is sharded")
+    p.add_argument("--sharded-edges", type=int, default=4_000_000)
+    p.add_argument("--sharded-feat", type=int, default=64)
     p.add_argument("--share-gpu", action="store_true",
                    help="rehearse the N>1 path on one GPU: all ranks use cuda:0, gloo instead of RCCL")
     return p.parse_args()
 
 
-def make_workload(args, rank):
+def make_workload(shape, replicas):
     from hypergef_amd import synth
-    if args.shape == "powerlaw":
+    if shape == "powerlaw":
         base = synth.powerlaw(1_000_000, 4_000_000, seed=3)
-        inc = base
-    else:
-        base = {"cora": synth.cora_shape, "citeseer": synth.citeseer_shape,
-                "pubmed": synth.pubmed_shape}[args.shape]()
-        inc = synth.replicate_block_diagonal(base, args.replicas)
-    return base, inc
+        return base, base
+    base = {"cora": synth.cora_shape, "citeseer": synth.citeseer_shape, "pubmed": synth.pubmed_shape}[shape]()
+    return base, synth.replicate_block_diagonal(base, replicas)
+
+
+def workload_name(shape, replicas, F):
+    if shape == "powerlaw":
+        return "power-law |V|=1M |E|=4M, F=%d" % F
+    return "%s-shape x%d block-diagonal batch, F=%d" % (shape, replicas, F)
 
 
 def timed_steps(fn, steps, sync, barrier):
+    """K calls of fn between two barrier + synchronize pairs: wall seconds, and the device seconds
+    between two HIP events recorded on the stream the kernels are launched on (torch's current
+    stream is the one the library receives)."""
     import torch
     barrier()
     sync()
@@ -89,25 +116,36 @@ def timed_steps(fn, steps, sync, barrier):
     return t1 - t0, ev0.elapsed_time(ev1) * 1e-3
 
 
-def cpu_baseline(base, inc, F, X_host):
-    """The oracle (a port of util::hyperaggr_reference_host, check.cuh:83-114)
-    on this box's host cores, rank 0 only, on a bounded sample."""
+def oracle_pass(base, inc, F, X_host, weighted, scales, time_it):
+    """The oracle on this box's host cores (rank 0, N = 1): the reference CPU path restated
+    (oracle/hg_oracle.c).  Returns (reference rows or None, rows checked, cpu_baseline dict or None).
+    Unweighted batches: util::hyperaggr_reference_host (check.cuh:83-114) over the whole batch, timed
+    for about 10 s.  One big hypergraph: TwostepSpMM_host (spmm.cuh:724-740), one pass (the fused host
+    path costs sum_v sum_e |e| row reads there: minutes).  Weighted: HGNN_check's arithmetic
+    (test/hgnn_test.py:56-63) on a prefix of the batch, checker only."""
     import numpy as np
     from oracle import oracle as orc
     orc.build()
-    # sample: the first S hypergraphs of the batch (whole workload if small)
     blocks = inc.M // base.M
+    if weighted:
+        S = min(blocks, 64)
+        Ms, Ns = base.M * S, base.N * S
+        ptr = inc.csrptr[:Ms + 1]
+        ind = inc.colind[:ptr[-1]]
+        H_ptr, H_ind = orc.transpose_csr(Ms, Ns, ptr, ind)
+        degE, degV, W = scales
+        ref = orc.hgnn_check(Ns, Ms, F, H_ptr, H_ind, ptr, ind, np.ascontiguousarray(X_host[:Ns]),
+                             degE[:Ms], degV[:Ns], W[:Ms])
+        return ref, Ns, None
     if blocks == 1 and inc.nnz > 2_000_000:
-        # one big hypergraph (power-law config): the fused host path costs sum_v sum_e |e| row
-        # reads, minutes at this size; time the reference's other CPU path, two spmm_reference_host
-        # calls (spmm.cuh:724-740), once over the whole graph
         H_ptr, H_ind = orc.transpose_csr(inc.M, inc.N, inc.csrptr, inc.colind)
         t0 = time.perf_counter()
-        orc.twostep_host(inc.N, inc.M, F, H_ptr, H_ind, inc.csrptr, inc.colind, X_host)
+        ref, _ = orc.twostep_host(inc.N, inc.M, F, H_ptr, H_ind, inc.csrptr, inc.colind, X_host)
         dt = time.perf_counter() - t0
-        return {"value": inc.nnz / dt, "unit": "edges/s", "cores": 1, "kind": "port",
-                "sample": "whole %s hypergraph, F=%d, one pass of the two-step host path (%.2f s)"
-                          % (base.name, F, dt)}
+        cpu = {"value": inc.nnz / dt, "unit": "edges/s", "cores": 1, "kind": "port",
+               "sample": "whole %s hypergraph, F=%d, one pass of the two-step host path (%.2f s)"
+                         % (base.name, F, dt)}
+        return ref, inc.N, cpu
     S = min(blocks, 1024)
     Ms, Ns = base.M * S, base.N * S
     ptr = inc.csrptr[:Ms + 1]
@@ -115,17 +153,20 @@ def cpu_baseline(base, inc, F, X_host):
     H_ptr, H_ind = orc.transpose_csr(Ms, Ns, ptr, ind)
     Xs = np.ascontiguousarray(X_host[:Ns])
     nnz_s = int(ptr[-1])
-    best, passes = None, 0
+    best, passes, ref = None, 0, None
     t_all = time.perf_counter()
-    while passes < 3 or (time.perf_counter() - t_all < 10 and passes < 50):  # about 10 s of CPU work
+    budget = 10 if time_it else 0
+    while passes < (3 if time_it else 1) or (time.perf_counter() - t_all < budget and passes < 50):
         t0 = time.perf_counter()
-        orc.hyperaggr_host(Ns, F, H_ptr, H_ind, ptr, ind, Xs)
+        ref = orc.hyperaggr_host(Ns, F, H_ptr, H_ind, ptr, ind, Xs)
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
         passes += 1
         if time.perf_counter() - t_all > 30:
             break
-    out = {"value": nnz_s / best, "unit": "edges/s", "cores": 1, "kind": "port",
+    if not time_it:
+        return ref, Ns, None
+    cpu = {"value": nnz_s / best, "unit": "edges/s", "cores": 1, "kind": "port",
            "sample": "first %d of %d %s hypergraphs of the batch, F=%d, best of %d passes (%.3f s each)"
                      % (S, blocks, base.name, F, passes, best)}
     try:
@@ -136,16 +177,205 @@ def cpu_baseline(base, inc, F, X_host):
             orc.hyperaggr_host(Ns, F, H_ptr, H_ind, ptr, ind, Xs, omp=True)
             dt = time.perf_counter() - t0
             best_mt = dt if best_mt is None else min(best_mt, dt)
-        out["all_cores"] = {"value": nnz_s / best_mt, "cores": threads}
-        out["host"] = "%d logical cpus" % (os.cpu_count() or 0)
+        cpu["all_cores"] = {"value": nnz_s / best_mt, "cores": threads}
+        cpu["host"] = "%d logical cpus" % (os.cpu_count() or 0)
     except Exception as exc:  # the baseline is informative; never fail the bench on it
-        out["all_cores_error"] = str(exc)
+        cpu["all_cores_error"] = str(exc)
+    return ref, Ns, cpu
+
+
+def parity_report(Y_dev, ref, nrows, inc):
+    """Timed output vs the oracle.  Bound per row: 1e-5 * max(1, |ref|) (BASELINE.json north_star)
+    plus the oracle's own worst-case rounding, u * (longest sequential chain feeding the row) --
+    nothing for the short rows of the dataset shapes, and what makes a vertex in 10^6 hyperedges
+    comparable at all: there the oracle's single fp32 chain is the less accurate side (it is up to
+    1e-3 off the float64 answer; the kernels' blocked sums stay within 1e-5 of it,
+    tests/test_gpu_parity.py::test_config4_powerlaw_full_size)."""
+    import numpy as np
+    y = Y_dev[:nrows].cpu().numpy()
+    sizes = np.diff(inc.csrptr).astype(np.int64)
+    deg = np.bincount(inc.colind, minlength=inc.N).astype(np.int64)[:nrows]
+    chain = deg + int(sizes.max() if sizes.size else 0)
+    err = np.abs(y - ref) / np.maximum(1.0, np.abs(ref))
+    tol = 1e-5 + U32 * np.where(chain > 64, chain, 0)[:, None]
+    bad = err > tol
+    return {"ok": not bool(bad.any()), "bit_exact": bool(np.array_equal(y, ref)), "max_rel_err": float(err.max()),
+            "rows_checked": int(nrows), "rows_total": int(inc.N), "mismatches": int(bad.sum()),
+            "bound": "1e-5*max(1,|ref|) + 2^-24 * (deg(v) + max|e|) for rows with chains longer than 64 terms",
+            "against": "oracle (CPU restatement of the reference host path), same input"}
+
+
+def run_config(shape, replicas, F, weighted, variant, steps, warmup, dev, sync, barrier, rank, opts_kw,
+               want_cpu, want_parity):
+    """Build one workload on `dev`, time `steps` aggregations, check the output.  Returns
+    (result dict, state for the extras)."""
+    import numpy as np
+    import torch
+    import hypergef_amd as hg
+    from hypergef_amd import plan as planmod, synth
+
+    base, inc = make_workload(shape, replicas)
+    X_host = synth.features_like_reference(inc.N, F, seed=100 + rank)
+    ptr = torch.from_numpy(inc.csrptr).to(dev)
+    ind = torch.from_numpy(inc.colind).to(dev)
+    X = torch.from_numpy(X_host).to(dev)
+    opts = planmod.make_opts(**opts_kw)
+    t0 = time.perf_counter()
+    plan = planmod.Plan.from_tensors(inc.N, ptr, ind, opts)
+    plan_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    resolved = plan.auto_variant(F) if variant == "auto" else variant
+    fused_shape = plan.prepare(F) if resolved == "fused" else None
+    prepare_s = time.perf_counter() - t0
+    degE = degV = W = None
+    scales_host = None
+    n_w = 0
+    if weighted:
+        hyperg = hg.HyperGraph.from_incidence(inc, dev, ngs=1 << 30)
+        degE, degV = hyperg.degE.reshape(-1), hyperg.degV.reshape(-1)
+        degE = torch.where(torch.isinf(degE), torch.zeros_like(degE), degE)
+        W = torch.rand(inc.M, device=dev) + 0.5
+        scales_host = (degE.cpu().numpy(), degV.cpu().numpy(), W.cpu().numpy())
+        n_w = 2
+    Y = torch.empty((inc.N, F), dtype=torch.float32, device=dev)
+    ws = torch.empty(max(plan.workspace_bytes(F), 256), dtype=torch.uint8, device=dev)
+
+    def step():
+        plan.aggregate(ptr, ind, X, degE, degV, W, variant=variant, out=Y, workspace=ws)
+
+    for _ in range(warmup):
+        step()
+    wall, dev_s = timed_steps(step, steps, sync, barrier)
+
+    launches = {"pull": 2, "fused": 1, "push_atomic": 1}[resolved]
+    dominant = {"pull": "gather_rows_kernel (hop 1 + hop 2 launches averaged)",
+                "fused": "fused_packed_kernel", "push_atomic": "push_groups_kernel"}[resolved]
+    info = fused_shape or {}
+    helper_launches = 0
+    if resolved == "fused":  # pre-pass / hub-pass / fixup launches of this schedule, timed inside the step
+        helper_launches = int(info.get("n_mat", 0) > 0) + int(info.get("n_hub", 0) > 0) + int(info.get("fixups", 0) > 0)
+    balg = b_alg(inc.N, inc.M, inc.nnz, F, n_w, degV is not None)
+    # the whole step's device time over its algorithmic bytes: helper launches count against the
+    # step, so a schedule that needs them is not flattered
+    step_s = dev_s / steps
+    achieved = balg / step_s / 1e9
+    name = workload_name(shape, replicas, F) + (", weighted (degE, degV, W)" if weighted else "")
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            entry = json.load(open(tpath)).get(name, {})
+            traffic = entry.get("bytes_per_step", entry.get("bytes_per_launch"))
+        except Exception:
+            traffic = None
+    res = {
+        "workload": name, "op": "hgnnaggr (degE, degV, W)" if weighted else "H*H^T*X (aggr_proto)",
+        "vertices": inc.N, "hyperedges": inc.M, "nnz": inc.nnz, "feat_len": F,
+        "variant": variant, "resolved_variant": resolved,
+        "ms_per_step": wall / steps * 1e3, "device_ms_per_step": step_s * 1e3,
+        "edges_per_s": inc.nnz * steps / wall,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": dominant,
+                     "algorithmic_bytes_per_step": balg, "avg_step_us": step_s * 1e6,
+                     "algorithmic_bytes_per_launch": balg / launches, "avg_launch_us": step_s / launches * 1e6,
+                     "launches_per_step": launches, "helper_launches_per_step": helper_launches},
+        "plan_build_s": plan_s, "fused_schedule_build_s": prepare_s, "fused_schedule": fused_shape,
+        "plan": {k: plan.info[k] for k in ("panels", "tasks", "fixups", "max_len", "short_max",
+                                            "panel_rows", "panel_nnz")},
+    }
+    cpu = None
+    if rank == 0 and (want_cpu or want_parity):
+        ref, nrows, cpu = oracle_pass(base, inc, F, X_host, weighted, scales_host, want_cpu)
+        if want_parity:
+            res["parity"] = parity_report(Y, ref, nrows, inc)
+    state = dict(base=base, inc=inc, plan=plan, ptr=ptr, ind=ind, X=X, Y=Y, ws=ws, opts=opts,
+                 degE=degE, degV=degV, W=W, wall=wall)
+    return res, cpu, state
+
+
+def single_graph_latency(state, F, dev, sync, shape):
+    """Latency of ONE hypergraph (what result.xlsx "fig7,fig9" reports, ms per aggregation)."""
+    import torch
+    from hypergef_amd import plan as planmod
+    base, X = state["base"], state["X"]
+    p1 = torch.from_numpy(base.csrptr).to(dev)
+    i1 = torch.from_numpy(base.colind).to(dev)
+    pl1 = planmod.Plan.from_tensors(base.N, p1, i1, state["opts"])
+    X1 = X[:base.N].contiguous()
+    Y1 = torch.empty((base.N, F), dtype=torch.float32, device=dev)
+    pl1.prepare(F)
+    ws1 = torch.empty(max(pl1.workspace_bytes(F), 256), dtype=torch.uint8, device=dev)
+    single = {}
+    for var in ("fused", "pull", "push_atomic"):
+        def f():
+            pl1.aggregate(p1, i1, X1, out=Y1, workspace=ws1, variant=var)
+        for _ in range(20):
+            f()
+        g = torch.cuda.CUDAGraph()
+        sync()
+        with torch.cuda.graph(g):
+            for _ in range(20):
+                f()
+        g.replay()
+        _, d = timed_steps(g.replay, 20, sync, lambda: None)
+        single[var + "_us"] = d / 400 * 1e6
+    single["reference_rtx3090_us"] = {"cora": 4.79, "citeseer": 3.70, "pubmed": 12.48}.get(shape)
+    single["note"] = "device time per aggregation, 20 back-to-back aggregations per hipGraph replay"
+    return single
+
+
+def sharded_section(args, dev, sync, barrier, rank, world):
+    """ONE hypergraph hyperedge-partitioned over the ranks (hypergef_amd.dist.ShardedAggregator,
+    default HIP operator per rank) with the dense exchange north_star names: sum all-reduce of the
+    [N, F] partials (every rank ends with Y), and reduce-scatter (rank r keeps its row block: half
+    the bytes).  Strong scaling: the work is fixed, so value = nnz / time."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from hypergef_amd import synth
+    from hypergef_amd.dist import ShardedAggregator
+    from hypergef_amd.plan import Plan
+    F = args.sharded_feat
+    inc = synth.powerlaw(args.sharded_nodes, args.sharded_edges, seed=3)
+    X = torch.from_numpy(synth.features_like_reference(inc.N, F, seed=7)).to(dev)  # replicated: same seed
+    out = {"workload": "power-law |V|=%d |E|=%d, F=%d, one hypergraph over %d ranks" % (inc.N, inc.M, F, world),
+           "nnz": inc.nnz, "scaling": "strong", "rccl_ranks": world,
+           "backend": dist.get_backend(), "bytes_per_rank_partial": inc.N * F * 4}
+    n = max(args.steps // 10, 5)
+    full = None
+    if rank == 0:  # single-GPU answer on rank 0's device: the sharded sum must reproduce it
+        ptr = torch.from_numpy(inc.csrptr).to(dev)
+        ind = torch.from_numpy(inc.colind).to(dev)
+        full = Plan.from_tensors(inc.N, ptr, ind).aggregate(ptr, ind, X)
+    for exchange in ("allreduce", "reduce_scatter"):
+        try:
+            agg = ShardedAggregator(inc, device=dev, exchange=exchange)
+            for _ in range(3):
+                Y = agg.aggregate(X)
+            w, _ = timed_steps(lambda: agg.aggregate(X), n, sync, barrier)
+            t = torch.tensor([w], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            w = float(t.item())
+            # the local kernel alone (no collective), for the split
+            loc = ShardedAggregator(inc, device=dev, exchange="none")
+            loc.aggregate(X)
+            wl, _ = timed_steps(lambda: loc.aggregate(X), n, sync, barrier)
+            entry = {"ms_per_step": w / n * 1e3, "value": inc.nnz * n / w, "unit": "edges/s",
+                     "local_kernel_ms": wl / n * 1e3, "shard_hyperedges": [agg.lo, agg.hi]}
+            if rank == 0:
+                lo, hi = agg.row_range() if exchange == "reduce_scatter" else (0, inc.N)
+                ref = full[lo:hi]
+                err = ((Y - ref).abs() / ref.abs().clamp(min=1.0)).max().item()
+                entry["max_rel_err_vs_single_gpu"] = err
+                entry["ok"] = bool(err <= 1e-5)
+            out[exchange] = entry
+        except Exception as exc:  # an extra: never let it take the headline line down with it
+            out[exchange] = {"error": str(exc)[:300]}
     return out
 
 
 def main():
     args = parse()
-    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -175,87 +405,43 @@ def main():
     def sync():
         torch.cuda.synchronize(dev)
 
-    import hypergef_amd as hg
-    from hypergef_amd import plan as planmod, synth
-
-    base, inc = make_workload(args, rank)
+    opts_kw = dict(short_max=args.short_max, panel_rows=args.panel_rows, panel_nnz=args.panel_nnz,
+                   xcd_remap=not args.no_xcd_remap, t_big=args.t_big, fused_tile_bytes=args.tile_bytes)
     F = args.feat
-    X_host = synth.features_like_reference(inc.N, F, seed=100 + rank)
-    ptr = torch.from_numpy(inc.csrptr).to(dev)
-    ind = torch.from_numpy(inc.colind).to(dev)
-    X = torch.from_numpy(X_host).to(dev)
-    opts = planmod.make_opts(short_max=args.short_max, panel_rows=args.panel_rows,
-                             panel_nnz=args.panel_nnz, xcd_remap=not args.no_xcd_remap,
-                             t_big=args.t_big, fused_tile_bytes=args.tile_bytes)
-    t0 = time.perf_counter()
-    plan = planmod.Plan.from_tensors(inc.N, ptr, ind, opts)
-    plan_s = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    fused_shape = plan.prepare(F) if plan.auto_variant(F) == "fused" or args.variant == "fused" else None
-    prepare_s = time.perf_counter() - t0
-    degE = degV = W = None
-    n_w = 0
-    if args.weighted:
-        hyperg = hg.HyperGraph.from_incidence(inc, dev, ngs=1 << 30)
-        degE, degV = hyperg.degE.reshape(-1), hyperg.degV.reshape(-1)
-        W = torch.ones(inc.M, device=dev)
-        n_w = 2
-    Y = torch.empty((inc.N, F), dtype=torch.float32, device=dev)
-    ws = torch.empty(max(plan.workspace_bytes(F), 256), dtype=torch.uint8, device=dev)
-
-    def step():
-        plan.aggregate(ptr, ind, X, degE, degV, W, variant=args.variant, out=Y, workspace=ws)
-
-    for _ in range(args.warmup):
-        step()
-    wall, dev_s = timed_steps(step, args.steps, sync, barrier)
+    one = world == 1
+    res, cpu, st = run_config(args.shape, args.replicas, F, args.weighted, args.variant, args.steps, args.warmup,
+                              dev, sync, barrier, rank, opts_kw,
+                              want_cpu=one and not args.no_cpu_baseline, want_parity=one and not args.no_parity)
+    wall = st["wall"]
     if world > 1:
         t = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
-
+    inc = st["inc"]
     total_nnz = inc.nnz * world
     value = total_nnz * args.steps / wall
-    resolved = plan.auto_variant(F) if args.variant == "auto" else args.variant
-    launches = 2 if resolved == "pull" else 1
-    dominant = {"pull": "gather_rows_kernel (hop 1 + hop 2 launches averaged)",
-                "fused": "fused_packed_kernel", "push_atomic": "push_groups_kernel"}[resolved]
-    balg = b_alg(inc.N, inc.M, inc.nnz, F, n_w)
-    kern_avg_s = dev_s / (args.steps * launches)
-    achieved = balg / launches / kern_avg_s / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    wl_name = "%s-shape x%d block-diagonal batch, F=%d" % (args.shape, args.replicas, F) \
-        if args.shape != "powerlaw" else "power-law |V|=1M |E|=4M, F=%d" % F
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(wl_name, {}).get("bytes_per_launch")
-        except Exception:
-            traffic = None
-
     out = {
         "metric": "aggregated edges/sec (fused V->E->V aggregation)",
         "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": wl_name, "op": "hgnnaggr" if args.weighted else "H*H^T*X (aggr_proto)",
+        "config": {"workload": res["workload"], "op": res["op"],
                    "vertices_per_gpu": inc.N, "hyperedges_per_gpu": inc.M, "nnz_per_gpu": inc.nnz,
-                   "feat_len": F, "variant": args.variant, "resolved_variant": resolved,
+                   "feat_len": F, "variant": args.variant, "resolved_variant": res["resolved_variant"],
                    "sharding": "hyperedge groups (one hypergraph batch per rank), no data-path collective"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": dominant,
-                     "algorithmic_bytes_per_launch": balg / launches,
-                     "avg_launch_us": kern_avg_s * 1e6, "launches_per_step": launches},
-        "hbm_gbs_algorithmic": balg * world * args.steps / wall / 1e9,
-        "plan_build_s": plan_s, "fused_schedule_build_s": prepare_s, "fused_schedule": fused_shape,
-        "plan": {k: plan.info[k] for k in ("panels", "tasks", "fixups", "max_len", "short_max",
-                                            "panel_rows", "panel_nnz")},
+        "roofline": res["roofline"],
+        "hbm_gbs_algorithmic": res["roofline"]["algorithmic_bytes_per_step"] * world * args.steps / wall / 1e9,
+        "plan_build_s": res["plan_build_s"], "fused_schedule_build_s": res["fused_schedule_build_s"],
+        "fused_schedule": res["fused_schedule"], "plan": res["plan"],
     }
+    if "parity" in res:
+        out["parity"] = res["parity"]
+    failed = "parity" in res and not res["parity"]["ok"]
 
     if not args.no_extras:
         # What a plain device copy X -> Y (the 2NF term of B_alg, no gather, no index traffic)
         # takes on this box: the practical floor of any kernel that reads X and writes Y once.
+        X, Y = st["X"], st["Y"]
         for _ in range(5):
             Y.copy_(X)
         _, d = timed_steps(lambda: Y.copy_(X), 50, sync, lambda: None)
@@ -264,76 +450,43 @@ def main():
                               "step_over_copy": (wall / args.steps) / copy_s,
                               "note": "torch copy of X into Y, same buffers; step_over_copy = "
                                       "aggregation step time / this"}
-        # latency of ONE hypergraph (what result.xlsx "fig7,fig9" reports, ms per aggregation)
         if args.shape != "powerlaw":
-            p1 = torch.from_numpy(base.csrptr).to(dev)
-            i1 = torch.from_numpy(base.colind).to(dev)
-            pl1 = planmod.Plan.from_tensors(base.N, p1, i1, opts)
-            X1 = X[:base.N].contiguous()
-            Y1 = torch.empty((base.N, F), dtype=torch.float32, device=dev)
-            ws1 = torch.empty(max(pl1.workspace_bytes(F), 256), dtype=torch.uint8, device=dev)
-            single = {}
-            for var in ("fused", "pull", "push_atomic"):
-                def f():
-                    pl1.aggregate(p1, i1, X1, out=Y1, workspace=ws1, variant=var)
-                for _ in range(20):
-                    f()
-                g = torch.cuda.CUDAGraph()
-                sync()
-                with torch.cuda.graph(g):
-                    for _ in range(20):
-                        f()
-                g.replay()
-                _, d = timed_steps(g.replay, 20, sync, lambda: None)
-                single[var + "_us"] = d / 400 * 1e6
-            single["reference_rtx3090_us"] = {"cora": 4.79, "citeseer": 3.70, "pubmed": 12.48}.get(args.shape)
-            single["note"] = "device time per aggregation, 20 back-to-back aggregations per hipGraph replay"
-            out["single_graph"] = single
-        if world > 1:
-            # dense variant: every rank ends with the full Y of the global batch
-            Yg = torch.zeros((inc.N * world, F), dtype=torch.float32, device=dev)
+            out["single_graph"] = single_graph_latency(st, F, dev, sync, args.shape)
+    del st
+    torch.cuda.empty_cache()
 
-            def step_ar():
-                plan.aggregate(ptr, ind, X, degE, degV, W, variant=args.variant, out=Y, workspace=ws)
-                Yg[rank * inc.N:(rank + 1) * inc.N].copy_(Y)
-                dist.all_reduce(Yg)
-            for _ in range(3):
-                step_ar()
-            w_ar, _ = timed_steps(step_ar, max(args.steps // 10, 5), sync, barrier)
-            t = torch.tensor([w_ar], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            n_ar = max(args.steps // 10, 5)
-            out["allreduce_dense"] = {"ms_per_step": float(t.item()) / n_ar * 1e3,
-                                      "value": total_nnz * n_ar / float(t.item()),
-                                      "bytes_allreduced": inc.N * world * F * 4}
-            if not args.share_gpu:  # gloo has no reduce_scatter
-                # SURVEY 8(e) option ii: the sum scattered, each rank keeps 1/world of the rows
-                Yrs = torch.empty((inc.N, F), dtype=torch.float32, device=dev)
+    if world > 1 and not args.no_extras:
+        out["sharded"] = sharded_section(args, dev, sync, barrier, rank, world)
 
-                def step_rs():
-                    plan.aggregate(ptr, ind, X, degE, degV, W, variant=args.variant, out=Y, workspace=ws)
-                    Yg[rank * inc.N:(rank + 1) * inc.N].copy_(Y)
-                    dist.reduce_scatter_tensor(Yrs, Yg)
-                try:  # an extra: never let it take the headline line down with it
-                    for _ in range(3):
-                        step_rs()
-                    w_rs, _ = timed_steps(step_rs, n_ar, sync, barrier)
-                    t = torch.tensor([w_rs], dtype=torch.float64, device=dev)
-                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                    out["reduce_scatter_dense"] = {"ms_per_step": float(t.item()) / n_ar * 1e3,
-                                                   "value": total_nnz * n_ar / float(t.item())}
-                except Exception as exc:
-                    out["reduce_scatter_dense"] = {"error": str(exc)[:200]}
+    if one and not args.no_configs and not args.no_extras:
+        # the other BASELINE configurations, same measurement, bounded step counts
+        configs = []
+        todo = [("pubmed", 64, 128, False), ("powerlaw", 1, 64, False), (args.shape, args.replicas, F, True)]
+        for shape, reps, feat, weighted in todo:
+            if (shape, reps, feat, weighted) == (args.shape, args.replicas, F, args.weighted):
+                continue
+            try:
+                r, c, s2 = run_config(shape, reps, feat, weighted, "auto", args.config_steps, 5, dev, sync, barrier,
+                                      rank, dict(xcd_remap=True), want_cpu=False, want_parity=not args.no_parity)
+                del s2
+                torch.cuda.empty_cache()
+                for k in ("plan", "plan_build_s"):
+                    r.pop(k, None)
+                failed = failed or ("parity" in r and not r["parity"]["ok"])
+                configs.append(r)
+            except Exception as exc:
+                configs.append({"workload": workload_name(shape, reps, feat), "error": str(exc)[:300]})
+        out["configs"] = configs
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(base, inc, F, X_host)
-    elif rank == 0:
-        out["cpu_baseline"] = None
     if rank == 0:
+        out["cpu_baseline"] = cpu if one and not args.no_cpu_baseline else None
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if failed:
+        print("bench.py: timed output does not match the oracle (see `parity`)", file=sys.stderr)
+        sys.exit(1)
 
 
 if __name__ == "__main__":

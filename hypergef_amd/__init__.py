@@ -13,7 +13,10 @@ from .ops import (HGNNAggr, HGNNAggrLinear, UniGNNConv, UniGNNConvdeg, UniGNNCon
                   hgnnaggr_linear)
 from .plan import Plan  # noqa: F401
 
-# The reference builds two top-level extension modules (setup.py:18,32-33).
+# The reference builds two top-level extension modules (setup.py:18,32-33).  They ship as real
+# files next to this package (`hgnnaggr.py`, `unignnaggr.py`: repo root, or site-packages after
+# `pip install .`), so `import hgnnaggr` needs no preparation.  The objects below are the same
+# surface for an embedder that has only this package directory on its path.
 hgnnaggr = types.ModuleType("hgnnaggr", "hgnnaggr (MI355X backend)")
 for _n in ("hgnnaggr", "hgnnaggr_mean", "hgnnaggr_max"):
     setattr(hgnnaggr, _n, getattr(ops, _n))
@@ -23,7 +26,17 @@ for _n in ("unignnaggrdeg", "unignnaggr", "unignnconvdeg", "unignnconv"):
 
 
 def install_dropin():
-    """Make `import hgnnaggr` / `import unignnaggr` resolve to this backend, so the
-    reference's wrappers (source/python/hgnnaggr.py:3, unignnconv.py:3) run unchanged."""
-    sys.modules["hgnnaggr"] = hgnnaggr
-    sys.modules["unignnaggr"] = unignnaggr
+    """Only needed when the top-level `hgnnaggr.py` / `unignnaggr.py` files are not on the import
+    path: registers equivalent modules in sys.modules so the reference's wrappers
+    (source/python/hgnnaggr.py:3, unignnconv.py:3) run unchanged.  Modules already importable
+    (or imported) are left alone."""
+    import importlib.util
+    for name, mod in (("hgnnaggr", hgnnaggr), ("unignnaggr", unignnaggr)):
+        if name in sys.modules:
+            continue
+        try:
+            found = importlib.util.find_spec(name) is not None
+        except (ImportError, ValueError):
+            found = False
+        if not found:
+            sys.modules[name] = mod

@@ -42,8 +42,13 @@ int resolve_opts(const hg_plan_opts *in, hg::Opts &o) {
     if (in->fused_tile_bytes > 0) o.fused_tile_bytes = in->fused_tile_bytes;
   }
   if (o.short_max > o.panel_nnz || o.split_len < o.short_max || o.panel_rows > 4096 ||
-      o.panel_nnz > 16384 || o.fused_tile_bytes > 65536) {
-    hg::set_error("hg_plan_opts: need short_max <= panel_nnz <= 16384, split_len >= short_max, panel_rows <= 4096, fused_tile_bytes <= 65536");
+      o.panel_nnz > 16384 || o.fused_tile_bytes > 131072) {
+    hg::set_error("hg_plan_opts: need short_max <= panel_nnz <= 16384, split_len >= short_max, panel_rows <= 4096, fused_tile_bytes <= 131072");
+    return HG_ERR_INVALID;
+  }
+  // what gather_rows_kernel stages per workgroup (launch_gather_t) must fit the CU's 160 KiB of LDS
+  if ((size_t)(4 * o.panel_rows + 1 + o.panel_nnz) * sizeof(int32_t) > (size_t)160 * 1024) {
+    hg::set_error("hg_plan_opts: panel_rows / panel_nnz need more than 160 KiB of LDS per workgroup");
     return HG_ERR_INVALID;
   }
   return HG_OK;
@@ -166,6 +171,14 @@ int get_fused(const hg_plan *cp, int32_t F, bool vec4, const hg::FusedSched **ou
         hg::set_error("fused schedule: internal error, panel exceeds its LDS budget");
         return HG_ERR_INVALID;
       }
+    }
+    // tile (+ 4 pad floats per row in the linear epilogue) | record | scale staging: launch_fused_t's carve-up
+    const size_t lds_need = (size_t)f.cap * (hg::fused_tile_row_floats(F, vec4) + 4) * 4 + (size_t)f.max_rec_words * 4 +
+                            (size_t)(2 * f.cap + f.rows_cap) * 4 + 16;
+    if (lds_need > (size_t)160 * 1024) {
+      hg::set_error("fused schedule: fused_tile_bytes = " + std::to_string(p->opts.fused_tile_bytes) + " needs " +
+                    std::to_string(lds_need) + " bytes of LDS per workgroup at this feature width (limit 163840)");
+      return HG_ERR_INVALID;
     }
     int rc = (p->opts.flags & HG_PLAN_HOST_ONLY) ? HG_OK : fused_upload(f, p->device_bytes);
     if (rc != HG_OK) {
@@ -478,6 +491,10 @@ int hg_plan_bind_scales(const hg_plan *cp, int32_t F, const float *degE, const f
   if (rc != HG_OK) return rc;
   hg::FusedSched *f = const_cast<hg::FusedSched *>(cf);
   std::lock_guard<std::mutex> lock(const_cast<hg_plan *>(cp)->fused_mu);
+  if (!degE && !degV && !W) {  // unbind: later calls gather their scales themselves
+    f->bound_degE = f->bound_W = f->bound_degV = nullptr;
+    return HG_OK;
+  }
   const size_t ns = f->eid_all.size(), nr = f->prow.size();
   if (!f->d_bsA && ns > 0) {
     HG_HIP(hipMalloc(reinterpret_cast<void **>(&f->d_bsA), ns * sizeof(float)));

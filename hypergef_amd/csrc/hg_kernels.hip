@@ -8,6 +8,7 @@
 // dwordx4 = one 128-byte line per row, 8 rows per wave instruction).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdlib>
 
 #include <type_traits>
@@ -789,13 +790,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LIN ? (LPR 
     // (issued before hop 2 they would hold K/4 more registers through it: 78 instead of 64 VGPRs)
     float bv[TW / 4];
     const LinSplit sp = lin_split(tid >> 6, a.F_out >> 4);
-    if (sp.active && !(a.debug & 512)) load_bfrag<TW / 4>(a.Wlin, sp.nt_first, tid & 63, bv);
+    if (sp.active && !(DBG && (a.debug & 512))) load_bfrag<TW / 4>(a.Wlin, sp.nt_first, tid & 63, bv);
     __syncthreads();  // every slot row has been read: the tile becomes the [rows][TW + 4] operand
 #pragma unroll
     for (int i = 0; i < 4; i++)
       if (r0 + i < r1) outr[i].store(tile + (r0 + i) * (TW + 4) + lcol);
     __syncthreads();
-    if (a.debug & 256) {  // ablation (timing only): no matrix work, the rows leave as they are
+    if (DBG && (a.debug & 256)) {  // ablation (timing only): no matrix work, the rows leave as they are
       const int q = min(a.F_out, TW) >> 2;
       for (int i = tid; i < nrows * q; i += 256) {
         const int r = i / q, c = (i - r * q) * 4;
@@ -874,8 +875,9 @@ static inline int next_pow2(int x) {
   return p;
 }
 
-// Experiment knobs, read once from the environment.  Defaults are the measured best
-// (profiles/r01_fused_experiments.md); nothing here changes results.
+// Experiment knobs.  The shipped library runs the measured best (profiles/r01_fused_experiments.md)
+// and reads nothing from the environment; the diagnostic build (`make tuning`, -DHG_TUNING) reads the
+// HG_* variables once.  Nothing here changes results.
 struct Tuning {
   int unroll = 4;        // HG_UNROLL = 4|8      : row loads in flight per lane, pull kernel
   int pipe = 0;          // HG_PIPE = 0|1        : two batches in flight, pull kernel
@@ -888,6 +890,7 @@ struct Tuning {
 static const Tuning &tuning() {
   static const Tuning t = [] {
     Tuning x;
+#ifdef HG_TUNING
     if (const char *e = getenv("HG_UNROLL")) x.unroll = atoi(e) == 8 ? 8 : 4;
     if (const char *e = getenv("HG_PIPE")) x.pipe = atoi(e) != 0;
     if (const char *e = getenv("HG_FUSED_U")) x.fused_u = atoi(e) == 16 ? 16 : 8;
@@ -895,9 +898,32 @@ static const Tuning &tuning() {
     if (const char *e = getenv("HG_FUSED_FAST")) x.fused_fast = atoi(e) != 0;
     if (const char *e = getenv("HG_FUSED_COLTILE")) x.fused_coltile = atoi(e) != 0;
     if (const char *e = getenv("HG_FUSED_DEBUG")) x.fused_debug = atoi(e);
+#endif
     return x;
   }();
   return t;
+}
+
+
+// Dynamic LDS above the 64 KiB default is an opt-in per kernel; gfx950 has 160 KiB per CU.
+constexpr size_t kLdsMax = 160 * 1024;
+#ifdef HG_TUNING
+constexpr bool kDbgFallback = true;   // diagnostic build: ablation switches stay in the generic instance
+#else
+constexpr bool kDbgFallback = false;
+#endif
+template <auto Kern, typename Args>
+static hipError_t launch_lds(dim3 grid, size_t lds, hipStream_t stream, const Args &a) {
+  static std::atomic<size_t> granted{64 * 1024};
+  if (lds > kLdsMax) return hipErrorInvalidValue;
+  if (lds > granted.load(std::memory_order_relaxed)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(Kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax);
+    if (e != hipSuccess) return e;
+    granted.store(kLdsMax, std::memory_order_relaxed);
+  }
+  hipLaunchKernelGGL(Kern, grid, dim3(256), lds, stream, a);
+  return hipGetLastError();
 }
 
 template <int LPR, int VEC>
@@ -907,16 +933,16 @@ static hipError_t launch_gather_t(const GatherArgs &a, int nfix, int nfix_l1, co
   const int nblocks = a.n_task_blocks + a.npanels;
   if (nblocks > 0) {
     const size_t lds = (size_t)(4 * a.panel_rows + 1 + a.panel_nnz) * sizeof(int32_t);
-    const dim3 grid(nblocks, col_tiles), block(256);
+    const dim3 grid(nblocks, col_tiles);
     const Tuning &t = tuning();
+    hipError_t e;
     if (t.unroll == 8) {
-      if (t.pipe) hipLaunchKernelGGL((gather_rows_kernel<LPR, VEC, 8, true>), grid, block, lds, stream, a);
-      else hipLaunchKernelGGL((gather_rows_kernel<LPR, VEC, 8, false>), grid, block, lds, stream, a);
+      e = t.pipe ? launch_lds<gather_rows_kernel<LPR, VEC, 8, true>>(grid, lds, stream, a)
+                 : launch_lds<gather_rows_kernel<LPR, VEC, 8, false>>(grid, lds, stream, a);
     } else {
-      if (t.pipe) hipLaunchKernelGGL((gather_rows_kernel<LPR, VEC, 4, true>), grid, block, lds, stream, a);
-      else hipLaunchKernelGGL((gather_rows_kernel<LPR, VEC, 4, false>), grid, block, lds, stream, a);
+      e = t.pipe ? launch_lds<gather_rows_kernel<LPR, VEC, 4, true>>(grid, lds, stream, a)
+                 : launch_lds<gather_rows_kernel<LPR, VEC, 4, false>>(grid, lds, stream, a);
     }
-    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
   const int per_block = 256 / LPR;
@@ -973,48 +999,46 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
         if (!fast || a.F != TW || a.rows_cap > 4 * (256 / LPR) || (a.F_out & 15)) return hipErrorInvalidValue;
         const size_t lds_l = lds_p + (size_t)a.cap * 4 * 4;  // + 4 pad floats per tile row
         const int spec = (a.Xe_mat ? 1 : 0) | ((a.degE || a.W) ? 2 : 0);
-#define HG_PKL(M, S) \
-  hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 8, true, M, S, false, true>), grid, dim3(256), lds_l, stream, ad)
+#define HG_PKL(M, S) return launch_lds<fused_packed_kernel<LPR, VEC, 8, true, M, S, false, true>>(grid, lds_l, stream, ad)
+#ifdef HG_TUNING
+        if (t.fused_debug & 768)  // ablations of the matrix phase (tools/linear_probe.py): diagnostic build only
+          return launch_lds<fused_packed_kernel<LPR, VEC, 8, true, true, true, true, true>>(grid, lds_l, stream, ad);
+#endif
         switch (spec) {
-          case 0: HG_PKL(false, false); break;
-          case 1: HG_PKL(true, false); break;
-          case 2: HG_PKL(false, true); break;
-          default: HG_PKL(true, true); break;
+          case 0: HG_PKL(false, false);
+          case 1: HG_PKL(true, false);
+          case 2: HG_PKL(false, true);
+          default: HG_PKL(true, true);
         }
 #undef HG_PKL
-        return hipGetLastError();
       } else {
         return hipErrorInvalidValue;
       }
     }
     if (fast) {
-      if (t.fused_debug) {  // ablation / stamp run: everything kept at run time
-        hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 8, true, true, true, true>), grid, dim3(256), lds_p, stream, ad);
-        return hipGetLastError();
-      }
+      if (t.fused_debug)  // ablation / stamp run (diagnostic build): everything kept at run time
+        return launch_lds<fused_packed_kernel<LPR, VEC, 8, true, true, true, true>>(grid, lds_p, stream, ad);
       // A grid that does not even fill the chip once is latency-bound, not occupancy-bound:
       // put every row gather of a group in flight at once (U = 16) instead of two batches.
       const bool u16 = t.fused_u == 16 || (t.fused_small16 && a.npanels <= 512);
       const int spec = (a.Xe_mat ? 1 : 0) | ((a.degE || a.W) ? 2 : 0);
-#define HG_PK(UU, M, S) \
-  hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, UU, true, M, S, false>), grid, dim3(256), lds_p, stream, ad)
+#define HG_PK(UU, M, S) return launch_lds<fused_packed_kernel<LPR, VEC, UU, true, M, S, false>>(grid, lds_p, stream, ad)
       if (u16) {
         switch (spec) {
-          case 0: HG_PK(16, false, false); break;
-          case 1: HG_PK(16, true, false); break;
-          case 2: HG_PK(16, false, true); break;
-          default: HG_PK(16, true, true); break;
+          case 0: HG_PK(16, false, false);
+          case 1: HG_PK(16, true, false);
+          case 2: HG_PK(16, false, true);
+          default: HG_PK(16, true, true);
         }
       } else {
         switch (spec) {
-          case 0: HG_PK(8, false, false); break;
-          case 1: HG_PK(8, true, false); break;
-          case 2: HG_PK(8, false, true); break;
-          default: HG_PK(8, true, true); break;
+          case 0: HG_PK(8, false, false);
+          case 1: HG_PK(8, true, false);
+          case 2: HG_PK(8, false, true);
+          default: HG_PK(8, true, true);
         }
       }
 #undef HG_PK
-      return hipGetLastError();
     }
   }
   if (a.Wlin) return hipErrorInvalidValue;
@@ -1024,14 +1048,11 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
                       (!a.Xe_mat || a.mat_bytes > 0);
     if (fast) {
       if (!a.Xe_mat && !a.degE && !a.W)
-        hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 8, true, false, false, false>), grid, dim3(256), lds_p, stream, ad);
-      else
-        hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 8, true, true, true, false>), grid, dim3(256), lds_p, stream, ad);
-      return hipGetLastError();
+        return launch_lds<fused_packed_kernel<LPR, VEC, 8, true, false, false, false>>(grid, lds_p, stream, ad);
+      return launch_lds<fused_packed_kernel<LPR, VEC, 8, true, true, true, false>>(grid, lds_p, stream, ad);
     }
   }
-  hipLaunchKernelGGL((fused_packed_kernel<LPR, VEC, 8, false, true, true, true>), grid, dim3(256), lds_p, stream, ad);
-  return hipGetLastError();
+  return launch_lds<fused_packed_kernel<LPR, VEC, 8, false, true, true, kDbgFallback>>(grid, lds_p, stream, ad);
 }
 
 hipError_t launch_linear_pack(int32_t F_out, int32_t F_in, const float *Wlin, float *wfrag, hipStream_t stream) {

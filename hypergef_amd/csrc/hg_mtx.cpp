@@ -30,6 +30,16 @@ std::string lower(std::string s) {
   return s;
 }
 
+struct FileGuard {  // closes on every exit path, exceptions included
+  FILE *f;
+  explicit FileGuard(FILE *f_) : f(f_) {}
+  ~FileGuard() {
+    if (f) std::fclose(f);
+  }
+  FileGuard(const FileGuard &) = delete;
+  FileGuard &operator=(const FileGuard &) = delete;
+};
+
 }  // namespace
 
 extern "C" {
@@ -48,12 +58,12 @@ int hg_mtx_read(const char *path, int32_t *nrow, int32_t *ncol, int64_t *nnz, in
     hg::set_error(std::string("File ") + path + " not found");
     return HG_ERR_INVALID;
   }
+  FileGuard guard(f);
   char line[1024];
   char banner[64], mtx[64], crd[64], field[64], symm[64];
   if (!std::fgets(line, sizeof(line), f) ||
       std::sscanf(line, "%63s %63s %63s %63s %63s", banner, mtx, crd, field, symm) != 5 ||
       std::strcmp(banner, "%%MatrixMarket") != 0 || lower(mtx) != "matrix" || lower(crd) != "coordinate") {
-    std::fclose(f);
     hg::set_error("Could not process this file.");
     return HG_ERR_INVALID;
   }
@@ -63,7 +73,6 @@ int hg_mtx_read(const char *path, int32_t *nrow, int32_t *ncol, int64_t *nnz, in
   const bool symmetric = lower(symm) == "symmetric";
   do {
     if (!std::fgets(line, sizeof(line), f)) {
-      std::fclose(f);
       hg::set_error("Could not process this file.");
       return HG_ERR_INVALID;
     }
@@ -71,7 +80,6 @@ int hg_mtx_read(const char *path, int32_t *nrow, int32_t *ncol, int64_t *nnz, in
   long long R = 0, C = 0, NZ = 0;
   if (std::sscanf(line, "%lld %lld %lld", &R, &C, &NZ) != 3 || R < 0 || C < 0 || NZ < 0 ||
       R > 0x7fffffffLL || C > 0x7fffffffLL || NZ > 0x7fffffffLL) {
-    std::fclose(f);
     hg::set_error("Could not process this file.");
     return HG_ERR_INVALID;
   }
@@ -82,27 +90,28 @@ int hg_mtx_read(const char *path, int32_t *nrow, int32_t *ncol, int64_t *nnz, in
       long long r, c;
       double dummy;
       if (std::fscanf(f, "%lld %lld", &r, &c) != 2) {
-        std::fclose(f);
         hg::set_error("Error: not enough rows in mtx file.");
         return HG_ERR_INVALID;
       }
       if (has_value && std::fscanf(f, "%lf", &dummy) != 1) dummy = 0;
       if (has_two && std::fscanf(f, "%lf %lf", &dummy, &dummy) != 2) dummy = 0;
       if (r < 1 || r > R || c < 1 || c > C) {
-        std::fclose(f);
         hg::set_error("mtx entry out of range at line " + std::to_string(i));
         return HG_ERR_INVALID;
       }
       coords.emplace_back((int32_t)(r - 1), (int32_t)(c - 1));
       if (symmetric && r != c) coords.emplace_back((int32_t)(c - 1), (int32_t)(r - 1));
     }
-    std::fclose(f);
     if (symmetric && R != C) {
       hg::set_error("symmetric mtx file must be square");
       return HG_ERR_INVALID;
     }
     std::sort(coords.begin(), coords.end());
     if (symmetric) coords.erase(std::unique(coords.begin(), coords.end()), coords.end());
+    if (coords.size() > (size_t)0x7fffffff) {  // mirrored entries count too: int32 row pointers below
+      hg::set_error("mtx file holds more than 2^31 - 1 entries after symmetric expansion");
+      return HG_ERR_INVALID;
+    }
     std::vector<int32_t> ptr((size_t)R + 1, 0), ind(coords.size());
     for (size_t i = 0; i < coords.size(); i++) {
       ptr[(size_t)coords[i].first + 1]++;

@@ -92,6 +92,17 @@ class ShardedAggregator:
             return self._reduce_scatter(Y)
         return Y
 
+    def apply(self, X, degE=None, degV=None, W=None):
+        """`aggregate` as an autograd node (training): gradient for X only, as the reference's
+        operators (hgnnaggr.cc:51-64).  Backward follows ops.set_backward: "reference" = the
+        forward operator on grad_out, "adjoint" = H diag(degE W) H^T diag(degV) grad; either way
+        each rank applies its shard's operator to the (replicated) grad_out and the partial
+        gradients are summed by the same collective, because X is replicated.  Needs a full Y
+        on every rank, i.e. exchange "allreduce" (or world 1)."""
+        if self.exchange == "reduce_scatter" and self.world > 1:
+            raise ValueError("autograd through exchange='reduce_scatter' is not supported: grad_out would be row-sharded")
+        return _ShardedFn.apply(self, X, degE, degV, W)
+
     def row_range(self, rank=None):
         """Rows of Y that `exchange="reduce_scatter"` leaves on `rank`: equal blocks of
         ceil(N / world) rows, the last one short."""
@@ -113,3 +124,22 @@ class ShardedAggregator:
         out = Y.new_empty((blk, F))
         dist.reduce_scatter_tensor(out, src, op=dist.ReduceOp.SUM)
         return out[:hi - lo]
+
+
+class _ShardedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, agg, X, degE, degV, W):
+        ctx.agg = agg
+        ctx.save_for_backward(degE, degV, W)
+        return agg.aggregate(X, degE, degV, W)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from . import ops
+        degE, degV, W = ctx.saved_tensors
+        g = grad_out.contiguous()
+        if ops._STATE["backward"] == "reference" or degV is None:
+            gx = ctx.agg.aggregate(g, degE, degV, W)
+        else:
+            gx = ctx.agg.aggregate(g * degV.reshape(-1, 1), degE, None, W)
+        return None, gx, None, None, None

@@ -100,20 +100,21 @@ class _SumAggr(torch.autograd.Function):
                 degE, degV, W):
         out = _forward((balan_key, balan_row, group_st, group_ed), csrptr_t, indices_t, node_feat,
                        degE, degV, W)
-        ctx.sched = (balan_key, balan_row, group_st, group_ed)
-        ctx.graph = (csrptr_t, indices_t)
-        ctx.scales = (degE, degV, W)
+        # The reference saves its inputs the same way (hgnnaggr.cc:44-46); node_feat is not needed
+        # (the operator is linear).  save_for_backward makes autograd raise if one of them is
+        # modified in place between forward and backward.
+        ctx.save_for_backward(balan_key, balan_row, group_st, group_ed, csrptr_t, indices_t, degE, degV, W)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         grad_out = grad_out.contiguous()
-        degE, degV, W = ctx.scales
-        csrptr_t, indices_t = ctx.graph
+        balan_key, balan_row, group_st, group_ed, csrptr_t, indices_t, degE, degV, W = ctx.saved_tensors
+        sched = (balan_key, balan_row, group_st, group_ed)
         if _STATE["backward"] == "reference" or degV is None:
-            g = _forward(ctx.sched, csrptr_t, indices_t, grad_out, degE, degV, W)
+            g = _forward(sched, csrptr_t, indices_t, grad_out, degE, degV, W)
         else:
-            g = _forward(ctx.sched, csrptr_t, indices_t, grad_out * degV.reshape(-1, 1), degE, None, W)
+            g = _forward(sched, csrptr_t, indices_t, grad_out * degV.reshape(-1, 1), degE, None, W)
         return (None,) * 6 + (g, None, None, None)
 
 
@@ -207,9 +208,7 @@ class _SumAggrLinear(torch.autograd.Function):
             Z = linear_rows(node_feat, wd) if linear_supported(F_in, F_out) and mode != "never" \
                 else torch.nn.functional.linear(node_feat, wd)
             out = _SumAggrLinear._aggr(csrptr_t, indices_t, Z, degE, degV, W)
-        ctx.graph = (csrptr_t, indices_t)
-        ctx.scales = (degE, degV, W)
-        ctx.save_for_backward(node_feat, weight)
+        ctx.save_for_backward(node_feat, weight, csrptr_t, indices_t, degE, degV, W)
         return out
 
     @staticmethod
@@ -222,9 +221,7 @@ class _SumAggrLinear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         grad_out = grad_out.contiguous()
-        node_feat, weight = ctx.saved_tensors
-        degE, degV, W = ctx.scales
-        csrptr_t, indices_t = ctx.graph
+        node_feat, weight, csrptr_t, indices_t, degE, degV, W = ctx.saved_tensors
         if _STATE["backward"] == "reference" or degV is None:
             dZ = _SumAggrLinear._aggr(csrptr_t, indices_t, grad_out, degE, degV, W)
         else:
@@ -244,16 +241,17 @@ class _AggrResLinear(torch.autograd.Function):
     dcb = <dT, R> (cb may be a tensor, e.g. 1 + eps)."""
 
     @staticmethod
-    def forward(ctx, csrptr_t, indices_t, node_feat, M, R, cb, degE, degV, W, ca, relu):
+    def forward(ctx, csrptr_t, indices_t, node_feat, M, R, cb, degE, degV, W, ca, relu, need_t):
         _check_feat(node_feat, "node_feat")
         _check_index(csrptr_t, "csrptr_t")
         _check_index(indices_t, "indices_t")
         degE, degV, W = _flat(degE), _flat(degV), _flat(W)
         N, F_in = node_feat.shape
         F_out = M.shape[0]
+        # cb is a Python float except where it is learned (UniGIN's 1 + eps): only then does reading
+        # it cost a device-to-host sync
         cbf = float(cb) if R is not None else 0.0
         variant = _STATE["variant"] if _STATE["variant"] != "push_groups" else "auto"
-        need_t = any(ctx.needs_input_grad[i] for i in (2, 3, 4, 5))
         Md = M.detach().contiguous()
         Rd = None if R is None else R.detach().contiguous()
         mode = _STATE["fuse_linear"]
@@ -271,18 +269,14 @@ class _AggrResLinear(torch.autograd.Function):
             out = T @ Md.t()
             if relu:
                 out = torch.relu(out)
-        ctx.graph = (csrptr_t, indices_t)
-        ctx.scales = (degE, degV, W)
         ctx.consts = (ca, cbf, relu)
-        ctx.save_for_backward(M, R if R is not None else M.new_empty(0), T if T is not None else M.new_empty(0), out)
+        ctx.save_for_backward(M, R, T, out, csrptr_t, indices_t, degE, degV, W)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        M, R, T, out = ctx.saved_tensors
+        M, R, T, out, csrptr_t, indices_t, degE, degV, W = ctx.saved_tensors
         ca, cbf, relu = ctx.consts
-        degE, degV, W = ctx.scales
-        csrptr_t, indices_t = ctx.graph
         dP = grad_out.contiguous()
         if relu:
             dP = torch.ops.aten.threshold_backward(dP, out, 0.0)  # relu's own backward: one vectorised kernel
@@ -295,17 +289,23 @@ class _AggrResLinear(torch.autograd.Function):
                 gx = _SumAggrLinear._aggr(csrptr_t, indices_t, g_in, degE, degV, W)
             else:
                 gx = _SumAggrLinear._aggr(csrptr_t, indices_t, g_in * degV.reshape(-1, 1), degE, None, W)
-        gR = dT * cbf if (R.numel() and ctx.needs_input_grad[4]) else None
-        gcb = (dT * R).sum() if (R.numel() and ctx.needs_input_grad[5]) else None
-        return None, None, gx, gM, gR, gcb, None, None, None, None, None
+        gR = dT * cbf if (R is not None and ctx.needs_input_grad[4]) else None
+        gcb = (dT * R).sum() if (R is not None and ctx.needs_input_grad[5]) else None
+        return None, None, gx, gM, gR, gcb, None, None, None, None, None, None
 
 
 def aggr_res_linear(csrptr_t, indices_t, node_feat, M, residual=None, ca=1.0, cb=0.0, degE=None, degV=None, W=None,
                     relu=False):
     """act((ca * Aggr(node_feat) + cb * residual) . M^T) in one pass where the widths allow
     (include/hg_aggr.h, hg_aggr_linear_res_f32).  cb may be a tensor (its gradient is returned)."""
-    cb_t = cb if isinstance(cb, torch.Tensor) else torch.tensor(float(cb), device=node_feat.device)
-    return _AggrResLinear.apply(csrptr_t, indices_t, node_feat, M, residual, cb_t, degE, degV, W, float(ca), bool(relu))
+    # a Python-number cb goes through as it is (no host-to-device copy, no sync to read it back)
+    cb_a = cb if isinstance(cb, torch.Tensor) else float(cb)
+    # T (the rows before the product) is written only if a backward pass can follow: Function.forward
+    # itself always runs with grad mode off and needs_input_grad set, so decide here
+    need_t = torch.is_grad_enabled() and any(
+        isinstance(t, torch.Tensor) and t.requires_grad for t in (node_feat, M, residual, cb_a))
+    return _AggrResLinear.apply(csrptr_t, indices_t, node_feat, M, residual, cb_a, degE, degV, W, float(ca),
+                                bool(relu), need_t)
 
 
 def hgnnaggr_linear(csrptr_t, indices_t, node_feat, weight, degE=None, degV=None, W=None):
@@ -338,13 +338,13 @@ class _MeanF1(torch.autograd.Function):
         _check_index(csrptr_t, "csrptr_t")
         s = _flat(degE) * _flat(W) / _edge_sizes(csrptr_t)
         s = torch.where(torch.isfinite(s), s, torch.zeros_like(s))  # empty hyperedge: never read
-        ctx.saved = (csrptr_t, indices_t, s, _flat(degV))
+        ctx.save_for_backward(csrptr_t, indices_t, s, _flat(degV))
         plan = cached_plan(node_feat.shape[0], csrptr_t, indices_t)
         return plan.aggregate(csrptr_t, indices_t, node_feat, s, _flat(degV), None)
 
     @staticmethod
     def backward(ctx, grad_out):
-        csrptr_t, indices_t, s, degV = ctx.saved
+        csrptr_t, indices_t, s, degV = ctx.saved_tensors
         plan = cached_plan(grad_out.shape[0], csrptr_t, indices_t)
         g = plan.aggregate(csrptr_t, indices_t, grad_out.contiguous(), s, degV, None)
         return None, None, g, None, None, None
@@ -371,13 +371,13 @@ class _MaxF1(torch.autograd.Function):
                                                     _stream_handle(dev)))
         plan = cached_plan(N, csrptr_t, indices_t)
         out = plan.gather_rows(1, csrptr_t, indices_t, Xe, degV, None)
-        ctx.saved = (csrptr_t, indices_t, degE, degV, W, record)
+        ctx.save_for_backward(csrptr_t, indices_t, degE, degV, W, record)
         ctx.mark_non_differentiable(record)
         return out, record
 
     @staticmethod
     def backward(ctx, grad_out, _grad_record):
-        csrptr_t, indices_t, degE, degV, W, record = ctx.saved
+        csrptr_t, indices_t, degE, degV, W, record = ctx.saved_tensors
         grad_out = grad_out.contiguous()
         N, F = grad_out.shape
         M = csrptr_t.numel() - 1

@@ -16,6 +16,9 @@ import torch
 from . import _lib
 
 
+_CACHE_LOCK = threading.Lock()
+
+
 def _ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -125,8 +128,10 @@ class Plan:
         return torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device), nbytes
 
     def aggregate(self, csrptr_t, colind_t, X, degE=None, degV=None, W=None, variant="auto",
-                  out=None, workspace=None):
-        """Y = degV . H (degE . W . (H^T X)) on X's device, current stream."""
+                  out=None, workspace=None, bind_scales=True):
+        """Y = degV . H (degE . W . (H^T X)) on X's device, current stream.
+        bind_scales: see _bind_scales; pass False for scale vectors whose contents change
+        without torch noticing (numpy / DLPack aliases, `.data` writes, other libraries)."""
         _check_feat(X, "node_feat")
         if X.shape[0] != self.N:
             raise ValueError("node_feat has %d rows, hypergraph has %d vertices" % (X.shape[0], self.N))
@@ -137,7 +142,7 @@ class Plan:
                 if t.numel() != n:
                     raise ValueError("%s must have %d elements, got %d" % (name, n, t.numel()))
         if (degE is not None or degV is not None or W is not None) and variant in ("auto", "fused"):
-            self._bind_scales(F, degE, degV, W, X.device)
+            self._bind_scales(F, degE, degV, W, X.device, bind_scales)
         Y = out if out is not None else torch.empty((self.N, F), dtype=torch.float32, device=X.device)
         if workspace is None:
             workspace, nbytes = self._workspace(F, X.device)
@@ -151,7 +156,7 @@ class Plan:
 
     def aggregate_linear(self, csrptr_t, colind_t, X, weight, degE=None, degV=None, W=None,
                          variant="auto", out=None, workspace=None, packed=None, residual=None, ca=1.0,
-                         cb=0.0, relu=False, t_out=None):
+                         cb=0.0, relu=False, t_out=None, bind_scales=True):
         """Y[N, F_out] = Aggr(X) . weight^T in one pass (hg_aggr_linear_f32); weight = nn.Linear.weight,
         [F_out, F_in]; packed = pack_linear(weight) if the caller keeps it across calls.
         With residual / ca / cb / relu / t_out: Y = act((ca * Aggr(X) + cb * residual) . weight^T) and
@@ -166,7 +171,7 @@ class Plan:
             raise ValueError("weight must be [F_out, F_in = %d]" % F_in)
         F_out = weight.shape[0]
         if packed is None:
-            packed = pack_linear(weight)
+            packed = packed_linear_cached(weight)
         elif packed.numel() != weight.numel():
             raise ValueError("packed does not belong to this weight")
         weight = packed
@@ -176,7 +181,7 @@ class Plan:
                 if t.numel() != n:
                     raise ValueError("%s must have %d elements, got %d" % (name, n, t.numel()))
         if (degE is not None or degV is not None or W is not None) and variant in ("auto", "fused"):
-            self._bind_scales(F_in, degE, degV, W, X.device)
+            self._bind_scales(F_in, degE, degV, W, X.device, bind_scales)
         Y = out if out is not None else torch.empty((self.N, F_out), dtype=torch.float32, device=X.device)
         if workspace is None:
             nbytes = int(_lib.lib().hg_aggr_linear_workspace_bytes(self._h, F_in))
@@ -194,23 +199,53 @@ class Plan:
                 _ptr(Y), _ptr(workspace), nbytes, _lib.VARIANTS[variant], _stream_handle(X.device)))
         return Y
 
-    def _bind_scales(self, F, degE, degV, W, device):
+    def _bind_scales(self, F, degE, degV, W, device, enable=True):
         """Degree / weight vectors are graph constants: pre-gather them into the fused
         schedule's panel order once (hg_plan_bind_scales) and again only when a tensor is
-        replaced or modified in place (data_ptr / torch version counter)."""
+        replaced or modified in place (data_ptr / torch version counter).
+
+        The rule for callers: the library compares addresses, this layer adds torch's version
+        counter.  A write that bumps neither (`t.data.mul_()`, a numpy or DLPack alias, another
+        library writing in place) is invisible -- call `plan.unbind()` after such a write, or
+        pass `bind_scales=False` for vectors that change that way; the kernel then gathers
+        degE / W / degV itself on every call (a few percent slower, always current).
+
+        The gather kernel runs on the stream current at binding time; a later call on another
+        stream waits for it through an event."""
         if not hasattr(self, "_bound"):
             self._bound, self._auto = {}, {}
         if F not in self._auto:
             self._auto[F] = self.auto_variant(F)
         if self._auto[F] != "fused":
             return
+        if not enable:
+            self.unbind(F)
+            return
         key = tuple(None if t is None else (t.data_ptr(), t._version) for t in (degE, degV, W))
-        if self._bound.get(F, (None,))[0] == key:
+        stream = torch.cuda.current_stream(device)
+        hit = self._bound.get(F)
+        if hit is not None and hit[0] == key:
+            if hit[2] != stream.cuda_stream:
+                stream.wait_event(hit[3])
             return
         with torch.cuda.device(device):
             _lib.check(_lib.lib().hg_plan_bind_scales(self._h, F, _ptr(degE), _ptr(degV), _ptr(W),
                                                       _stream_handle(device)))
-        self._bound[F] = (key, degE, degV, W)  # keep the tensors (and so their addresses) alive
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        # keep the tensors (and so their addresses) alive; remember where the gather was enqueued
+        self._bound[F] = (key, (degE, degV, W), stream.cuda_stream, ev)
+
+    def unbind(self, F=None):
+        """Forget the pre-gathered scale vectors (of feature width F, or all): the next call either
+        binds afresh or, with bind_scales=False, reads degE / W / degV directly."""
+        bound = getattr(self, "_bound", {})
+        for f in ([F] if F is not None else list(bound)):
+            if f in bound:
+                dev = next((t.device for t in bound[f][1] if t is not None), self.device)
+                with torch.cuda.device(dev):
+                    _lib.check(_lib.lib().hg_plan_bind_scales(self._h, f, None, None, None, _stream_handle(dev)))
+                del bound[f]
 
     def gather_rows(self, hop, csrptr_t, colind_t, src, scaleA=None, scaleB=None):
         """One hop: hop 0 = H^T src (rows = hyperedges), hop 1 = H src."""
@@ -251,6 +286,28 @@ def pack_linear(weight):
     return wfrag
 
 
+_PACK_CACHE = collections.OrderedDict()
+_PACK_CACHE_MAX = 64
+
+
+def packed_linear_cached(weight):
+    """pack_linear(weight), kept until the weight is replaced or modified in place (data_ptr /
+    torch version counter: an optimizer step bumps it): inference re-uses one packing per layer
+    instead of launching the pack kernel on every forward."""
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape), str(weight.device))
+    with _CACHE_LOCK:
+        hit = _PACK_CACHE.get(key)
+        if hit is not None:
+            _PACK_CACHE.move_to_end(key)
+            return hit[0]
+    packed = pack_linear(weight)
+    with _CACHE_LOCK:
+        _PACK_CACHE[key] = (packed, weight)  # the weight stays alive: its address cannot be recycled under the key
+        while len(_PACK_CACHE) > _PACK_CACHE_MAX:
+            _PACK_CACHE.popitem(last=False)
+    return packed
+
+
 def linear_rows(X, weight, packed=None, out=None):
     """X . weight^T on the library's own fp32-MFMA rows kernel (hg_linear_rows_f32): for the
     tall-skinny products of this path it is 1.1-1.5x rocBLAS at K <= 64 and on par at K = 128."""
@@ -260,7 +317,7 @@ def linear_rows(X, weight, packed=None, out=None):
     if X.dim() != 2 or X.shape[1] != F_in:
         raise ValueError("X must be [rows, F_in = %d]" % F_in)
     if packed is None:
-        packed = pack_linear(weight)
+        packed = packed_linear_cached(weight)
     Y = out if out is not None else torch.empty((X.shape[0], F_out), dtype=torch.float32, device=X.device)
     with torch.cuda.device(X.device):
         _lib.check(_lib.lib().hg_linear_rows_f32(X.shape[0], F_in, F_out, _ptr(X), _ptr(packed), _ptr(Y),
@@ -320,7 +377,6 @@ def _check_feat(t, name, device=None):
 
 # ------------------------------------------------------------------ plan cache
 _CACHE = collections.OrderedDict()
-_CACHE_LOCK = threading.Lock()
 _CACHE_MAX = 32
 _DEFAULT_OPTS = None
 

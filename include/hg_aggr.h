@@ -167,8 +167,11 @@ HG_API int hg_plan_prepare(const hg_plan *plan, int32_t F, hg_fused_info *info);
  * order for feature width F.  Later hg_aggr_fused_f32 calls (fused variant) that pass
  * exactly these three pointers read the scales with coalesced loads instead of one
  * scattered 4-byte gather per hyperedge slot.  Re-bind after changing the vectors'
- * contents; passing other pointers simply bypasses the binding.  Allocates on the
- * first call per width (not capturable); enqueues one small kernel on `stream`. */
+ * contents; passing other pointers simply bypasses the binding, and binding three NULL
+ * pointers removes it (later calls gather their scales themselves: the safe choice for
+ * vectors another library rewrites in place).  The binding is keyed on addresses only.
+ * Allocates on the first call per width (not capturable); enqueues one small kernel on
+ * `stream` -- a caller that aggregates on a different stream orders the two itself. */
 HG_API int hg_plan_bind_scales(const hg_plan *plan, int32_t F, const float *degE,
                                const float *degV, const float *W, hg_stream_t stream);
 /* The variant HG_VARIANT_AUTO resolves to for feature width F (builds the

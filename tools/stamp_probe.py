@@ -2,6 +2,8 @@
 """Per-phase cycle shares of fused_panel_kernel (diagnostic build path: HG_FUSED_DEBUG=32)."""
 import ctypes, os, sys
 os.environ["HG_FUSED_DEBUG"] = os.environ.get("STAMP_DEBUG", "32")
+ROOT_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("HG_AGGR_LIB", os.path.join(ROOT_, "hypergef_amd", "lib", "libhgaggr_stamps.so"))  # `make stamps`
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
