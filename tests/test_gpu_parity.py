@@ -793,8 +793,11 @@ def test_config4_powerlaw_full_size(hg, oracle):
     vertex in 1.5 M hyperedges, hyperedges of up to 4096 members) against the oracle's two-step
     host path (TwostepSpMM_host, spmm.cuh:724-740) -- with guard bands around Y and the workspace.
     Rows the oracle and the kernels sum in the same order (short chains) must agree bit for bit;
-    all rows meet the 1e-5 bound against the float64 answer and the reference test's allclose
-    against the fp32 oracle, whose own sequential sums of 10^6 terms are the less accurate side."""
+    ALL rows meet the 1e-5 bound against the float64 answer.  Against the fp32 oracle: the 1e-5 bound
+    plus the oracle's own worst-case rounding u * (chain length) -- its single sequential chain over
+    a hub vertex's 1.5 M hyperedges is up to 1e-3 off the float64 answer (measured), the kernels'
+    blocked sums are not -- and the reference test's allclose(1e-4, 1e-6) on every row whose chains
+    stay below 512 terms (u * 512 = 3e-5)."""
     from hypergef_amd.plan import Plan
     inc = synth.powerlaw(1_000_000, 4_000_000, seed=3)
     F = 64
@@ -810,8 +813,15 @@ def test_config4_powerlaw_full_size(hg, oracle):
     # vertices whose own row and all of whose hyperedges are short: one sequential chain each
     has_big = np.add.reduceat(np.concatenate([big_e[H_ind], [0]]), np.minimum(H_ptr[:-1], inc.nnz))[:inc.N]
     has_big[np.diff(H_ptr) == 0] = 0
-    short_rows = (np.diff(H_ptr) <= sm) & (has_big == 0)
+    deg = np.diff(H_ptr).astype(np.int64)
+    short_rows = (deg <= sm) & (has_big == 0)
     assert short_rows.sum() > inc.N // 4
+    chain = deg + int(esz.max())                      # longest sequential fp32 chain feeding a row of the oracle
+    oracle_tol = (1e-5 + 2.0 ** -24 * np.where(chain > 64, chain, 0))[:, None]
+    mid_rows = (deg <= 512) & (np.maximum.reduceat(np.concatenate([esz[H_ind], [0]]),
+                                                   np.minimum(H_ptr[:-1], inc.nnz))[:inc.N] <= 512)
+    mid_rows[deg == 0] = True
+    assert mid_rows.sum() > inc.N * 0.8 and (chain > 100000).sum() > 10
     G = 4096
     nws = (plan.workspace_bytes(F) + 3) // 4
     for variant in ("auto", "pull"):
@@ -823,9 +833,10 @@ def test_config4_powerlaw_full_size(hg, oracle):
         for buf, n in ((ybuf, inc.N * F), (wbuf, nws)):
             assert bool((buf[:G] == 7.25).all()) and bool((buf[G + n:] == 7.25).all()), variant
         y = Y.cpu().numpy()
-        assert np.allclose(y, ref, rtol=1e-4, atol=1e-6), variant        # test/hgnn_test.py:92
         bad = ~_tol_ok(y, truth)
         assert not bad.any(), (variant, np.abs(y - truth).max(), np.argwhere(bad)[:4])
+        assert (np.abs(y - ref) <= oracle_tol * np.maximum(1.0, np.abs(ref))).all(), variant
+        assert np.allclose(y[mid_rows], ref[mid_rows], rtol=1e-4, atol=1e-6), variant    # test/hgnn_test.py:92
         if variant == "pull":
             assert np.array_equal(y[short_rows], ref[short_rows]), "short chains keep the CPU order"
         else:
