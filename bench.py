@@ -63,6 +63,8 @@ def parse():
     p.add_argument("--variant", default="auto", choices=["auto", "pull", "fused", "push_atomic"])
     p.add_argument("--t-big", type=int, default=0)
     p.add_argument("--tile-bytes", type=int, default=0)
+    p.add_argument("--fused-steps", type=int, default=0)
+    p.add_argument("--no-hub-pass", action="store_true")
     p.add_argument("--weighted", action="store_true", help="hgnnaggr (degE, degV, W) instead of H H^T X")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-parity", action="store_true", help="skip the oracle comparison of the timed output")
@@ -406,7 +408,8 @@ def main():
         torch.cuda.synchronize(dev)
 
     opts_kw = dict(short_max=args.short_max, panel_rows=args.panel_rows, panel_nnz=args.panel_nnz,
-                   xcd_remap=not args.no_xcd_remap, t_big=args.t_big, fused_tile_bytes=args.tile_bytes)
+                   xcd_remap=not args.no_xcd_remap, t_big=args.t_big, fused_tile_bytes=args.tile_bytes,
+                   fused_steps=args.fused_steps, hub_pass=not args.no_hub_pass)
     F = args.feat
     one = world == 1
     res, cpu, st = run_config(args.shape, args.replicas, F, args.weighted, args.variant, args.steps, args.warmup,

@@ -18,6 +18,7 @@ HG_VARIANT_FUSED = 3
 HG_PLAN_HOST_ONLY = 1
 HG_PLAN_NO_XCD_REMAP = 2
 HG_PLAN_DFS_ORDER = 4
+HG_PLAN_NO_HUB_PASS = 8
 
 VARIANTS = {"auto": HG_VARIANT_AUTO, "pull": HG_VARIANT_PULL, "push_atomic": HG_VARIANT_PUSH_ATOMIC,
             "fused": HG_VARIANT_FUSED}
@@ -44,13 +45,17 @@ class PlanOpts(ctypes.Structure):
     _fields_ = [("short_max", ctypes.c_int32), ("split_len", ctypes.c_int32),
                 ("panel_rows", ctypes.c_int32), ("panel_nnz", ctypes.c_int32),
                 ("flags", ctypes.c_int32), ("t_big", ctypes.c_int32),
-                ("fused_tile_bytes", ctypes.c_int32)]
+                ("fused_tile_bytes", ctypes.c_int32), ("fused_steps", ctypes.c_int32)]
 
 
 class FusedInfo(ctypes.Structure):
     _fields_ = [("cap", ctypes.c_int32), ("t_big", ctypes.c_int32), ("vdeg_max", ctypes.c_int32),
                 ("panels", ctypes.c_int32), ("n_mat", ctypes.c_int32), ("n_hub", ctypes.c_int32),
-                ("slots", ctypes.c_int64), ("member_entries", ctypes.c_int64)]
+                ("slots", ctypes.c_int64), ("member_entries", ctypes.c_int64),
+                ("n_split", ctypes.c_int32), ("fixups", ctypes.c_int32),
+                ("hub_rounds", ctypes.c_int32), ("hub_workgroups", ctypes.c_int32),
+                ("hub_entries", ctypes.c_int64), ("hub_pairs", ctypes.c_int64),
+                ("partial_rows", ctypes.c_int64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

@@ -40,6 +40,7 @@ int resolve_opts(const hg_plan_opts *in, hg::Opts &o) {
     o.flags = in->flags;
     if (in->t_big > 0) o.t_big = in->t_big;
     if (in->fused_tile_bytes > 0) o.fused_tile_bytes = in->fused_tile_bytes;
+    if (in->fused_steps > 0) o.fused_steps = in->fused_steps;
   }
   if (o.short_max > o.panel_nnz || o.split_len < o.short_max || o.panel_rows > 4096 ||
       o.panel_nnz > 16384 || o.fused_tile_bytes > 131072) {
@@ -102,25 +103,24 @@ int fused_upload(hg::FusedSched &f, int64_t &bytes) {
   UP(mat_ptr, d_mat_ptr);
   UP(mat_ind, d_mat_ind);
   UP(mat_eid, d_mat_eid);
-  UP(hub_ptr, d_hub_ptr);
-  UP(hub_ind, d_hub_ind);
-  UP(hub_vid, d_hub_vid);
   UP(rec, d_rec);
   UP(rec_tab, d_rec_tab);
   UP(eid_all, d_eid_all);
+  UP(fixups, d_fixups);
+  UP(hub.vslot0, hub.d_vslot0);
+  UP(hub.rec, hub.d_rec);
+  UP(hub.rec_tab, hub.d_rec_tab);
+  UP(hub.wg_first, hub.d_wg_first);
 #undef UP
-  if ((rc = sched_upload(f.mat_sched, bytes)) != HG_OK) return rc;
-  return sched_upload(f.hub_sched, bytes);
+  return sched_upload(f.mat_sched, bytes);
 }
 
 void fused_free(hg::FusedSched &f) {
-  void *ptrs[] = {f.d_prow, f.d_mat_ptr,
-                  f.d_mat_ind, f.d_mat_eid, f.d_hub_ptr, f.d_hub_ind, f.d_hub_vid, f.d_rec, f.d_rec_tab,
-                  f.d_eid_all, f.d_bsA, f.d_bsB, f.d_bsD};
+  void *ptrs[] = {f.d_prow, f.d_mat_ptr, f.d_mat_ind, f.d_mat_eid, f.d_rec, f.d_rec_tab, f.d_eid_all, f.d_bsA,
+                  f.d_bsB, f.d_bsD, f.d_fixups, f.hub.d_vslot0, f.hub.d_rec, f.hub.d_rec_tab, f.hub.d_wg_first};
   for (void *q : ptrs)
     if (q) (void)hipFree(q);
   sched_free(f.mat_sched);
-  sched_free(f.hub_sched);
 }
 
 // Capacities of a fused panel for feature width F: `cap` hyperedge slots (rows of the
@@ -130,6 +130,10 @@ void fused_caps(const hg_plan *p, int32_t F, bool vec4, int32_t &cap, int32_t &m
   const int c = std::max(16, std::min(256, p->opts.fused_tile_bytes / row_bytes));
   cap = c / 16 * 16;
   mem_cap = cap * 4;
+  if (p->opts.fused_steps > 0) {  // whole batches of the kernel's row loads: steps x lane groups
+    const int32_t ng = 256 / (hg::fused_tile_row_floats(F, vec4) / (vec4 ? 4 : 1));
+    mem_cap = std::max(p->opts.t_big, std::min(mem_cap, p->opts.fused_steps * ng));
+  }
 }
 
 // The F-dependent part of the plan, built on first use (guarded by the plan's mutex).
@@ -137,28 +141,33 @@ int get_fused(const hg_plan *cp, int32_t F, bool vec4, const hg::FusedSched **ou
   hg_plan *p = const_cast<hg_plan *>(cp);
   int32_t cap, mem_cap;
   fused_caps(p, F, vec4, cap, mem_cap);
-  const int32_t ng = 256 / (hg::fused_tile_row_floats(F, vec4) / (vec4 ? 4 : 1));  // lane groups per workgroup
-  const int64_t key = ((int64_t)cap * 1000000 + mem_cap) * 1000 + ng;
+  const int32_t row_floats = hg::fused_tile_row_floats(F, vec4);
+  const int32_t ng = 256 / (row_floats / (vec4 ? 4 : 1));  // lane groups per workgroup
+  // The hub pass reads X and the materialised table through buffer descriptors (row index below 2^24,
+  // tables below 2 GiB) and exists for 16-byte lanes of at least 16 floats per row.
+  const bool allow_hub = vec4 && F >= 16 && p->N < (1 << 24) && (int64_t)p->N * F * 4 < ((int64_t)1 << 31) &&
+                         (int64_t)p->M * F * 4 < ((int64_t)1 << 31);
+  const int64_t key = (((int64_t)cap * 1000000 + mem_cap) * 1000 + ng) * 2 + (allow_hub ? 1 : 0);
   std::lock_guard<std::mutex> lock(p->fused_mu);
   auto it = p->fused.find(key);
   if (it == p->fused.end()) {
     hg::FusedSched f;
     try {
       hg::build_fused(p->N, p->M, p->ptr_t.data(), p->ind_t.data(), p->ptr_v.data(), p->ind_v.data(),
-                      p->opts, cap, mem_cap, ng, f);
+                      p->opts, cap, mem_cap, ng, row_floats, allow_hub, f);
       // A small hypergraph is launch-bound.  If the default schedule needs a materialisation
       // launch only because of a few longish hyperedges, try recomputing them too and keep
       // that schedule when the launch saved (~5 us) outweighs its longer streams (~0.08 us
       // per step of the longest panel): one citeseer-shape hypergraph 15.8 -> 8.2 us,
       // coauthor_cora-shape 12.6 -> 9.6 us at F = 32; pubmed-shape keeps materialising.
-      if (p->nnz <= (1 << 18) && f.n_mat > 0 && f.n_hub == 0 && p->sched[0].max_len * 4 <= mem_cap) {
+      if (p->nnz <= (1 << 18) && f.n_mat > 0 && f.n_split == 0 && p->sched[0].max_len * 4 <= mem_cap) {
         hg::Opts o = p->opts;
         o.t_big = std::max(o.t_big, p->sched[0].max_len);
         hg::FusedSched alt;
         hg::build_fused(p->N, p->M, p->ptr_t.data(), p->ind_t.data(), p->ptr_v.data(), p->ind_v.data(), o, cap,
-                        mem_cap, ng, alt);
+                        mem_cap, ng, row_floats, allow_hub, alt);
         const double cost_default = 10.0 + 0.08 * f.max_steps, cost_alt = 5.0 + 0.08 * alt.max_steps;
-        if (alt.n_mat == 0 && alt.n_hub == 0 && cost_alt < cost_default) f = std::move(alt);
+        if (alt.n_mat == 0 && alt.n_split == 0 && cost_alt < cost_default) f = std::move(alt);
       }
     } catch (const std::bad_alloc &) {
       hg::set_error("fused schedule: host allocation failed");
@@ -173,8 +182,9 @@ int get_fused(const hg_plan *cp, int32_t F, bool vec4, const hg::FusedSched **ou
       }
     }
     // tile (+ 4 pad floats per row in the linear epilogue) | record | scale staging: launch_fused_t's carve-up
-    const size_t lds_need = (size_t)f.cap * (hg::fused_tile_row_floats(F, vec4) + 4) * 4 + (size_t)f.max_rec_words * 4 +
-                            (size_t)(2 * f.cap + f.rows_cap) * 4 + 16;
+    const size_t lds_need = std::max((size_t)f.cap * (row_floats + 4) * 4 + (size_t)f.max_rec_words * 4 +
+                                         (size_t)(2 * f.cap + f.rows_cap) * 4 + 16,
+                                     f.hub.K > 0 ? hg::hub_pass_lds_bytes(f.hub.cap, row_floats, f.hub.max_rec_words) : 0);
     if (lds_need > (size_t)160 * 1024) {
       hg::set_error("fused schedule: fused_tile_bytes = " + std::to_string(p->opts.fused_tile_bytes) + " needs " +
                     std::to_string(lds_need) + " bytes of LDS per workgroup at this feature width (limit 163840)");
@@ -187,11 +197,13 @@ int get_fused(const hg_plan *cp, int32_t F, bool vec4, const hg::FusedSched **ou
     }
     it = p->fused.emplace(key, std::move(f)).first;
   }
+  p->fused_by_width[(int64_t)F * 2 + (vec4 ? 1 : 0)] = &it->second;
   *out = &it->second;
   return HG_OK;
 }
 
-// workspace carve-up: [Xe: M*F][partials hop 0][partials hop 1]
+// workspace carve-up.  Pull: [Xe: M*F][partials hop 0][partials hop 1].  Fused (the same buffer):
+// [Xe_mat: n_mat*F][partials of the materialisation pre-pass][partial rows of hubs and pieces].
 struct Carve {
   size_t xe, part[2], total;
 };
@@ -205,6 +217,26 @@ Carve carve(const hg_plan *p, int32_t F) {
   }
   c.total = off;
   return c;
+}
+struct FusedCarve {
+  size_t mat_part, part, total;
+};
+FusedCarve fused_carve(const hg::FusedSched &f, int32_t F) {
+  FusedCarve c;
+  c.mat_part = round256((size_t)f.n_mat * F * sizeof(float));
+  c.part = c.mat_part + round256((size_t)f.mat_sched.nslots * F * sizeof(float));
+  c.total = c.part + round256((size_t)f.n_part * F * sizeof(float));
+  return c;
+}
+// The pull layout always fits a pull call; a fused schedule that exists for this width (built by
+// hg_plan_prepare, hg_plan_auto_variant or an earlier call) may need more for its partial rows.
+size_t workspace_need(const hg_plan *cp, int32_t F) {
+  hg_plan *p = const_cast<hg_plan *>(cp);
+  size_t need = carve(p, F).total;
+  std::lock_guard<std::mutex> lock(p->fused_mu);
+  for (const auto &kv : p->fused_by_width)
+    if (kv.first / 2 == F) need = std::max(need, fused_carve(*kv.second, F).total);
+  return need;
 }
 
 // What HG_VARIANT_AUTO resolves to.  Measured over the 13 dataset shapes, single graphs and
@@ -242,19 +274,24 @@ int pick_variant_uncached(const hg_plan *plan, int32_t F, bool vec4, int32_t *va
   *variant = HG_VARIANT_PULL;
   const bool small = plan->nnz <= (1 << 18);  // launch-bound: work per launch hardly matters
   if (!small && plan->small_nnz_frac < 0.2) return HG_OK;  // not worth building the schedule
-  // hubs first: that part of the rule needs only the classification, not the panels
   int32_t cap, mem_cap;
   fused_caps(plan, F, vec4, cap, mem_cap);
-  int64_t n_mat = 0, n_hub = 0;
-  hg::classify_fused(plan->N, plan->M, plan->ptr_t.data(), plan->ptr_v.data(), plan->ind_v.data(), plan->opts,
-                     cap, mem_cap, &n_mat, &n_hub);
-  // small graphs: a hub pass is a third dependent launch, which alone costs more than the pull path
-  const bool hubs_ok = small ? n_hub == 0
-                             : n_hub * 16 <= plan->N && !(n_hub > 0 && n_mat * 4 > 3 * (int64_t)plan->M);
-  if (!hubs_ok) return HG_OK;
+  if (small) {
+    // a vertex too big for a panel means partial rows and a fixup launch: a third dependent launch,
+    // which alone costs more than the pull path on a launch-bound graph
+    int64_t n_mat = 0, n_big = 0;
+    hg::classify_fused(plan->N, plan->M, plan->ptr_t.data(), plan->ptr_v.data(), plan->ind_v.data(), plan->opts,
+                       cap, mem_cap, &n_mat, &n_big);
+    if (n_big > 0) return HG_OK;
+  }
   int rc = get_fused(plan, F, vec4, f);
   if (rc != HG_OK) return rc;
-  const bool work_ok = small || (*f)->pmem_entries <= 5 * plan->nnz;
+  // Row gathers of the fused path (panels + hub pass + materialisation) against the pull path's
+  // 2 nnz: measured (profiles/r01_variant_choice.md, r02) the panels win up to about 5 nnz stream
+  // entries -- one launch, no Xe round trip, re-gathered rows mostly L2 hits.
+  const hg::FusedSched &fs = **f;
+  const int64_t mat_nnz = fs.mat_ptr.empty() ? 0 : fs.mat_ptr.back();
+  const bool work_ok = small || fs.pmem_entries + fs.hub.stream_entries + mat_nnz <= 5 * plan->nnz;
   if (work_ok) *variant = HG_VARIANT_FUSED;
   return HG_OK;
 }
@@ -312,7 +349,7 @@ int check_call(const hg_plan *plan, int32_t F, const void *workspace, size_t wor
     hg::set_error("feature matrix too large");
     return HG_ERR_INVALID;
   }
-  const size_t need = carve(plan, F).total;
+  const size_t need = workspace_need(plan, F);
   if (need > 0 && (!workspace || workspace_bytes < need)) {
     hg::set_error("workspace too small: need " + std::to_string(need) + " bytes, got " +
                   std::to_string(workspace_bytes));
@@ -535,11 +572,18 @@ int hg_plan_prepare(const hg_plan *p, int32_t F, hg_fused_info *info) {
     info->vdeg_max = f->vdeg_max;
     info->panels = (int32_t)f->panels.size();
     info->n_mat = f->n_mat;
-    info->n_hub = f->n_hub;
+    info->n_hub = f->hub.K;
     info->member_entries = f->pmem_entries;
     int64_t slots = 0;
     for (const auto &pn : f->panels) slots += pn.nslots;
     info->slots = slots;
+    info->n_split = f->n_split;
+    info->fixups = (int32_t)f->fixups.size();
+    info->hub_rounds = (int32_t)f->hub.rec_tab.size();
+    info->hub_workgroups = f->hub.K > 0 ? f->hub.nwg : 0;
+    info->hub_entries = f->hub.stream_entries;
+    info->hub_pairs = f->hub.pairs;
+    info->partial_rows = f->n_part;
   }
   return HG_OK;
 }
@@ -552,7 +596,11 @@ __attribute__((visibility("default"))) int hg_debug_read_stamps(unsigned long lo
 
 size_t hg_plan_workspace_bytes(const hg_plan *p, int32_t F) {
   if (!p || F <= 0) return 0;
-  return carve(p, F).total;
+  // size for what HG_VARIANT_AUTO will run: resolving it builds the fused schedule if that is the choice
+  int32_t variant = HG_VARIANT_PULL;
+  const hg::FusedSched *f = nullptr;
+  (void)pick_variant(p, F, F % 4 == 0, &variant, &f);
+  return workspace_need(p, F);
 }
 
 int hg_gather_rows_f32(const hg_plan *plan, int32_t hop, int32_t F, const int32_t *csrptr_t,
@@ -679,17 +727,48 @@ static int aggr_impl(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
   }
   if (variant == HG_VARIANT_FUSED) {
     if (!f && (rc = get_fused(plan, F, vec4, &f)) != HG_OK) return rc;
-    // (a) materialised hyperedges (long ones, and those of hub vertices): Xe_mat rows
+    const FusedCarve fc = fused_carve(*f, F);
+    if (fc.total > workspace_bytes) {
+      hg::set_error("workspace too small for the fused schedule: need " + std::to_string(fc.total) + " bytes, got " +
+                    std::to_string(workspace_bytes) +
+                    " (hg_plan_workspace_bytes covers it once hg_plan_prepare has built the schedule)");
+      return HG_ERR_WORKSPACE;
+    }
+    float *partial = reinterpret_cast<float *>(ws + fc.part);
+    const int64_t xb = (int64_t)plan->N * F * 4, mb = (int64_t)f->n_mat * F * 4;
+    const int32_t x_bytes = xb < ((int64_t)1 << 31) ? (int32_t)xb : 0;
+    const int32_t mat_bytes = mb < ((int64_t)1 << 31) ? (int32_t)mb : 0;
+    // (a) materialised hyperedges (more than t_big members): Xe_mat rows
     if (f->n_mat > 0) {
       rc = run_sched(plan, f->mat_sched, F, f->d_mat_ptr, f->d_mat_ind, X, degE, W, f->d_mat_eid,
-                     nullptr, Xe, reinterpret_cast<float *>(ws + c.part[0]), s);
+                     nullptr, Xe, reinterpret_cast<float *>(ws + fc.mat_part), s);
       if (rc != HG_OK) return rc;
     }
-    // (b) hub vertices: plain row gathers over Xe_mat
-    if (f->n_hub > 0) {
-      rc = run_sched(plan, f->hub_sched, F, f->d_hub_ptr, f->d_hub_ind, Xe, degV, nullptr,
-                     f->d_hub_vid, f->d_hub_vid, Y, reinterpret_cast<float *>(ws + c.part[1]), s);
-      if (rc != HG_OK) return rc;
+    // (b) register hubs: persistent workgroups stream the hyperedges, running sums in registers
+    if (f->hub.K > 0) {
+      hg::HubArgs h;
+      h.rec = f->hub.d_rec;
+      h.rec_tab = f->hub.d_rec_tab;
+      h.wg_first = f->hub.d_wg_first;
+      h.vslot0 = f->hub.d_vslot0;
+      h.nwg = f->hub.nwg;
+      h.ng = f->hub.ng;
+      h.cap = f->hub.cap;
+      h.max_rec_words = f->hub.max_rec_words;
+      h.X = X;
+      h.Xe_mat = f->n_mat > 0 ? Xe : nullptr;
+      h.degE = degE;
+      h.W = W;
+      h.partial = partial;
+      h.F = F;
+      h.x_bytes = x_bytes;
+      h.mat_bytes = mat_bytes;
+      h.nrows_x = plan->N;
+      h.nrows_mat = f->n_mat;
+      h.n_heavy = f->hub.n_heavy;
+      for (int q = 0; q < hg::kHubHeavy; q++) h.hslot0[q] = f->hub.hslot0[q];
+      hipError_t e = hg::launch_hub_pass(h, vec4, s);
+      if (e != hipSuccess) return hip_fail("hub_pass launch", e);
     }
     // (c) everything else: vertex panels with the hyperedge sums staged in LDS
     hg::FusedArgs a;
@@ -700,6 +779,7 @@ static int aggr_impl(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
     a.W = W;
     a.degV = degV;
     a.Y = Y;
+    a.partial = partial;
     a.F = F;
     a.cap = f->cap;
     a.rows_cap = f->rows_cap;
@@ -709,16 +789,17 @@ static int aggr_impl(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
     a.eid_all = f->d_eid_all;
     a.max_rec_words = f->max_rec_words;
     a.ng = f->ng;
-    const int64_t xb = (int64_t)plan->N * F * 4, mb = (int64_t)f->n_mat * F * 4;
-    a.x_bytes = xb < ((int64_t)1 << 31) ? (int32_t)xb : 0;
-    a.mat_bytes = mb < ((int64_t)1 << 31) ? (int32_t)mb : 0;
+    a.x_bytes = x_bytes;
+    a.mat_bytes = mat_bytes;
     a.nrows_x = plan->N;
+    a.nrows_mat = f->n_mat;
     // scales pre-gathered into panel order, if the caller bound exactly these arrays
     const bool bound = (degE || degV || W) && f->bound_degE == degE && f->bound_W == W && f->bound_degV == degV;
     a.bsA = bound ? f->d_bsA : nullptr;
     a.bsB = bound ? f->d_bsB : nullptr;
     a.bsD = bound ? f->d_bsD : nullptr;
-    if (lin && f->n_hub == 0 && vec4) {  // hub rows are produced outside the panels: no epilogue then
+    // rows produced outside the panels (hubs, split vertices) get no epilogue: two-step then
+    if (lin && f->fixups.empty() && vec4) {
       a.Wlin = lin->Wlin;
       a.F_out = lin->F_out;
       a.epi = lin->epi;
@@ -731,6 +812,11 @@ static int aggr_impl(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
     }
     hipError_t e = hg::launch_fused(a, vec4, s);
     if (e != hipSuccess) return hip_fail("fused_panel launch", e);
+    // (d) hubs and split vertices: Y[v] = degV[v] * (sum of the vertex's partial rows), fixed order
+    if (!f->fixups.empty()) {
+      e = hg::launch_fixups(f->d_fixups, (int)f->fixups.size(), f->n_fix_l1, F, partial, Y, degV, vec4, s);
+      if (e != hipSuccess) return hip_fail("fixup launch", e);
+    }
     return HG_OK;
   }
   // hop 1: Xe[e] = ((sum_{u in e} X[u]) * degE[e]) * W[e]

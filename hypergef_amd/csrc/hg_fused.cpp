@@ -4,38 +4,132 @@
 // its vertices touch become "slots" of an LDS tile.  A slot is either
 // recomputed inside the workgroup from its member rows of X (small hyperedges)
 // or loaded from a materialised table Xe_mat (hyperedges with more than t_big
-// members, and every hyperedge of a hub vertex), so the M x F hyperedge
-// feature matrix never makes a round trip through HBM for the bulk of the graph.
+// members), so the M x F hyperedge feature matrix never makes a round trip
+// through HBM for the bulk of the graph.
+//
+// Vertices with more incident hyperedges than a panel can hold take one of two roads:
+//  * register hubs (HubPass, hg_internal.h): the heaviest vertices of a large graph keep their
+//    running sums in registers of persistent workgroups that stream all hyperedges containing a
+//    hub, each hyperedge sum computed once per pass however many hubs it feeds;
+//  * split vertices: the incidence list is cut into pieces of at most vdeg_max hyperedges, every
+//    piece is an ordinary panel row that writes a partial sum instead of a row of Y.
+// Both leave partial rows that the fixup pass adds up in a fixed order (deterministic).
 #include <algorithm>
+#include <numeric>
 
 #include "hg_internal.h"
 
 namespace hg {
 
 void pack_records(FusedSched &f, int32_t ng, int32_t idle);
+static void build_hub_pass(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_t, const int32_t *ptr_v,
+                           const std::vector<uint8_t> &is_mat, const std::vector<int32_t> &mat_id,
+                           const std::vector<int32_t> &hub_of, const std::vector<int32_t> &parts,
+                           int32_t t_big, FusedSched &f, std::vector<Fixup> &finals);
 
 // The classification step of build_fused alone (what the AUTO rule needs first): how many
-// vertices would be hubs and how many hyperedges materialised for these capacities.
+// hyperedges would be materialised and how many vertices exceed a panel (hubs or split rows).
 void classify_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ptr_v, const int32_t *ind_v,
-                    const Opts &o, int32_t cap, int32_t mem_cap, int64_t *n_mat, int64_t *n_hub) {
+                    const Opts &o, int32_t cap, int32_t mem_cap, int64_t *n_mat, int64_t *n_big) {
+  (void)ind_v;
   const int32_t t_big = std::max(1, std::min(o.t_big, mem_cap));
   const int32_t vdeg_max = std::max(1, std::min(std::min(cap, cap * 2), mem_cap / t_big));
-  std::vector<uint8_t> is_mat((size_t)M, 0);
-  *n_hub = 0;
-  for (int32_t e = 0; e < M; e++)
-    if (ptr_t[e + 1] - ptr_t[e] > t_big) is_mat[e] = 1;
-  for (int32_t v = 0; v < N; v++)
-    if (ptr_v[v + 1] - ptr_v[v] > vdeg_max) {
-      (*n_hub)++;
-      for (int32_t p = ptr_v[v]; p < ptr_v[v + 1]; p++) is_mat[ind_v[p]] = 1;
-    }
   *n_mat = 0;
-  for (int32_t e = 0; e < M; e++) *n_mat += is_mat[e];
+  for (int32_t e = 0; e < M; e++)
+    if (ptr_t[e + 1] - ptr_t[e] > t_big) (*n_mat)++;
+  *n_big = 0;
+  for (int32_t v = 0; v < N; v++)
+    if (ptr_v[v + 1] - ptr_v[v] > vdeg_max) (*n_big)++;
+}
+
+// Geometry of the hub pass for a tile row of `row_floats` floats: 1024 threads, LPR lanes per row.
+static void hub_geometry(int32_t ng_panel, int32_t row_floats, int32_t tile_bytes, HubPass &h) {
+  h.bs = 1024;
+  h.ng = ng_panel * 4;  // 1024 / LPR where ng_panel = 256 / LPR
+  h.R = kHubRows;
+  h.cap = std::max(16, std::min(1024, tile_bytes / (row_floats * 4))) / 16 * 16;
+  h.cap = std::max(h.cap, (h.ng + 15) / 16 * 16);  // the end-of-launch reduction parks one row per lane group in the tile
+  // stream entries per round: two full batches of the kernel's 8 row loads in flight per lane
+  // (a third, nearly empty batch would cost a whole round trip), never less than one slot's worth
+  h.mem_cap = std::min(h.cap * 4, 16 * h.ng);
+  h.pair_cap = std::max(h.ng * h.R, std::min(h.cap * 8, 8192));  // (hub, slot) pairs per round
+}
+
+// The kernel prefetches the next round's record with two dwordx4 per thread (32 KB at most) and LDS
+// holds two records beside the tile and the hot rows: a record stays below 24 KB.  Upper bound of a
+// round's record: the longest-first packing puts at most ceil(entries / ng) + (longest slot) steps on a
+// lane group.
+constexpr int32_t kHubRecWords = 6144;
+static int32_t hub_rec_bound(const HubPass &h, int32_t entries, int32_t longest, int32_t nslots, int32_t npairs) {
+  return 16 + h.ng + ((entries + h.ng - 1) / h.ng + longest + 1) * h.ng + nslots + (h.ng * h.R + 1) / 2 + (npairs + 1) / 2 + 4;
+}
+
+// Hop-1 entry stream of one record: the slots are spread over `ng` lane groups, longest first, each
+// to the least loaded group, so every group walks about the same number of steps; the stream is laid
+// out [step][group].  Recomputed slots (member rows of X) come first; materialised slots (one row of
+// the materialised table each) follow from step `steps_x` on, dealt round-robin -- the kernels walk
+// the two phases with one buffer descriptor each instead of testing every entry.  Idle entries name
+// the row one past the table of their phase (no flags).  Slot ids are renumbered in (group,
+// completion order): newid[k] = new id of slot k, gslots[g] = first id of group g.
+struct SlotRange {
+  int32_t m0, m1;   // entry words in `mem`: row index, bit 31 = row of the materialised table
+  uint32_t hmask;   // heavy-hub mask for the last entry (hub pass; bits 24..27)
+};
+struct PackedStream {
+  int32_t steps = 0, steps_x = 0;
+  std::vector<int32_t> stream, newid, gslots;
+};
+static void pack_stream(const std::vector<SlotRange> &slots, const int32_t *mem, int32_t ng, int32_t idle_x,
+                        int32_t idle_m, uint32_t row_mask, PackedStream &out) {
+  const int32_t ns = (int32_t)slots.size();
+  std::vector<int32_t> order_x, mats;
+  for (int32_t k = 0; k < ns; k++) {
+    const bool mat = slots[k].m1 - slots[k].m0 == 1 && ((uint32_t)mem[slots[k].m0] & 0x80000000u);
+    (mat ? mats : order_x).push_back(k);
+  }
+  std::stable_sort(order_x.begin(), order_x.end(), [&](int32_t a, int32_t b) {
+    return (slots[a].m1 - slots[a].m0) > (slots[b].m1 - slots[b].m0);
+  });
+  std::vector<int32_t> load((size_t)ng, 0);
+  std::vector<std::vector<int32_t>> members((size_t)ng), mmembers((size_t)ng);
+  for (int32_t k : order_x) {
+    int32_t best = 0;
+    for (int32_t g = 1; g < ng; g++)
+      if (load[g] < load[best]) best = g;
+    members[best].push_back(k);
+    load[best] += slots[k].m1 - slots[k].m0;
+  }
+  out.steps_x = 0;
+  for (int32_t g = 0; g < ng; g++) out.steps_x = std::max(out.steps_x, load[g]);
+  for (size_t i = 0; i < mats.size(); i++) mmembers[i % (size_t)ng].push_back(mats[i]);
+  const int32_t mat_steps = ((int32_t)mats.size() + ng - 1) / ng;
+  out.steps = out.steps_x + mat_steps;
+  out.stream.assign((size_t)out.steps * ng, idle_x);
+  for (size_t i = (size_t)out.steps_x * ng; i < out.stream.size(); i++) out.stream[i] = idle_m;
+  out.newid.assign((size_t)ns, 0);
+  out.gslots.assign((size_t)ng, 0);
+  int32_t next = 0;
+  auto emit = [&](int32_t g, int32_t k, int32_t &s) {
+    out.newid[k] = next++;
+    for (int32_t p = slots[k].m0; p < slots[k].m1; p++, s++) {
+      const uint32_t w = (uint32_t)mem[p];
+      const uint32_t mat = (w & 0x80000000u) ? 0x40000000u : 0u;
+      const uint32_t last = (p + 1 == slots[k].m1) ? (0x80000000u | (slots[k].hmask << 24)) : 0u;
+      out.stream[(size_t)s * ng + g] = (int32_t)((w & row_mask) | mat | last);
+    }
+  };
+  for (int32_t g = 0; g < ng; g++) {
+    out.gslots[g] = next;
+    int32_t s = 0;
+    for (int32_t k : members[g]) emit(g, k, s);
+    s = out.steps_x;
+    for (int32_t k : mmembers[g]) emit(g, k, s);
+  }
 }
 
 void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_t,
                  const int32_t *ptr_v, const int32_t *ind_v, const Opts &o, int32_t cap,
-                 int32_t mem_cap, int32_t ng, FusedSched &f) {
+                 int32_t mem_cap, int32_t ng, int32_t row_floats, bool allow_hub, FusedSched &f) {
   f = FusedSched();
   f.cap = cap;
   f.rows_cap = cap;
@@ -44,37 +138,65 @@ void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_
   f.t_big = std::max(1, std::min(o.t_big, f.mem_cap));
   // a single row must always fit into an empty panel
   f.vdeg_max = std::max(1, std::min(std::min(cap, f.vslot_cap), f.mem_cap / f.t_big));
+  const int64_t nnz = ptr_t[M];
 
-  std::vector<uint8_t> is_mat((size_t)M, 0), is_hub((size_t)N, 0);
-  for (int32_t e = 0; e < M; e++)
-    if (ptr_t[e + 1] - ptr_t[e] > f.t_big) is_mat[e] = 1;
-  for (int32_t v = 0; v < N; v++)
-    if (ptr_v[v + 1] - ptr_v[v] > f.vdeg_max) {
-      is_hub[v] = 1;
-      f.n_hub++;
-      for (int32_t p = ptr_v[v]; p < ptr_v[v + 1]; p++) is_mat[ind_v[p]] = 1;
-    }
-
-  // compact CSR of the materialised hyperedges
+  // materialised hyperedges: compact CSR over their members
+  std::vector<uint8_t> is_mat((size_t)M, 0);
   std::vector<int32_t> mat_id((size_t)M, -1);
   f.mat_ptr.push_back(0);
   for (int32_t e = 0; e < M; e++)
-    if (is_mat[e]) {
+    if (ptr_t[e + 1] - ptr_t[e] > f.t_big) {
+      is_mat[e] = 1;
       mat_id[e] = f.n_mat++;
       f.mat_eid.push_back(e);
       f.mat_ind.insert(f.mat_ind.end(), ind_t + ptr_t[e], ind_t + ptr_t[e + 1]);
       f.mat_ptr.push_back((int32_t)f.mat_ind.size());
     }
-  // compact CSR of the hub vertices over materialised rows
-  f.hub_ptr.push_back(0);
-  for (int32_t v = 0; v < N; v++)
-    if (is_hub[v]) {
-      f.hub_vid.push_back(v);
-      for (int32_t p = ptr_v[v]; p < ptr_v[v + 1]; p++) f.hub_ind.push_back(mat_id[ind_v[p]]);
-      f.hub_ptr.push_back((int32_t)f.hub_ind.size());
-    }
   build_sched(f.n_mat, f.mat_ptr.data(), o, f.mat_sched);
-  build_sched(f.n_hub, f.hub_ptr.data(), o, f.hub_sched);
+
+  // ---- vertices that do not fit a panel: register hubs, or pieces ------------------------------
+  // big[v]: 1 = register hub, 2 = split into pieces
+  std::vector<uint8_t> big((size_t)N, 0);
+  std::vector<int32_t> cand;
+  for (int32_t v = 0; v < N; v++)
+    if (ptr_v[v + 1] - ptr_v[v] > f.vdeg_max) {
+      big[v] = 2;
+      cand.push_back(v);
+    }
+  std::vector<int32_t> hub_of((size_t)N, -1), parts;
+  HubPass &hp = f.hub;
+  hub_geometry(ng, row_floats, o.hub_tile_bytes, hp);
+  const int32_t kHubMinDeg = o.hub_min_deg;
+  // one hyperedge of t_big members and a pair for every hub must fit an empty round's record
+  allow_hub = allow_hub && hub_rec_bound(hp, f.t_big, f.t_big, 1, hp.ng * hp.R) <= kHubRecWords;
+  if (allow_hub && !(o.flags & HG_PLAN_NO_HUB_PASS) && nnz >= o.hub_min_nnz && !cand.empty()) {
+    auto deg = [&](int32_t v) { return ptr_v[v + 1] - ptr_v[v]; };
+    std::stable_sort(cand.begin(), cand.end(), [&](int32_t a, int32_t b) { return deg(a) > deg(b); });
+    const int32_t vmax = hp.ng * hp.R;
+    int64_t top = 0;
+    for (size_t i = 0; i < cand.size() && (int32_t)i < vmax && deg(cand[i]) >= kHubMinDeg; i++) top += deg(cand[i]);
+    if (top * 5 >= nnz) {  // the pass streams (nearly) every hyperedge: worth it for a fifth of the incidences
+      // the heaviest few (each at least 1/512 of all incidences) ride on stream flags, not on virtual rows
+      int64_t heavy_sum = 0;
+      while (hp.n_heavy < kHubHeavy && hp.n_heavy < (int32_t)cand.size() && deg(cand[hp.n_heavy]) >= kHubMinDeg &&
+             (int64_t)deg(cand[hp.n_heavy]) * 512 >= nnz)
+        heavy_sum += deg(cand[hp.n_heavy++]);
+      // no virtual row heavier than half a lane group's fair share of a round
+      const int64_t wmax = std::max<int64_t>(1, (top - heavy_sum) / (2 * (int64_t)hp.ng));
+      int32_t nv = 0;
+      for (size_t i = 0; i < cand.size() && deg(cand[i]) >= kHubMinDeg; i++) {
+        const bool heavy = (int32_t)i < hp.n_heavy;
+        const int32_t p = heavy ? 0 : (int32_t)std::min<int64_t>(64, (deg(cand[i]) + wmax - 1) / wmax);
+        if (nv + p > vmax) break;
+        nv += p;
+        hub_of[cand[i]] = hp.K++;
+        hp.vid.push_back(cand[i]);
+        parts.push_back(p);
+        big[cand[i]] = 1;
+      }
+      hp.nv = nv;
+    }
+  }
 
   // Row order: depth-first post-order over the bipartite vertex/hyperedge graph,
   // so that a panel (a run of this order) holds vertices that share hyperedges:
@@ -89,7 +211,7 @@ void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_
     };
     std::vector<Frame> st;
     for (int32_t root = 0; root < N; root++) {
-      if (vis[root] || is_hub[root]) continue;
+      if (vis[root] || big[root]) continue;
       vis[root] = 1;
       st.push_back(Frame{root, ptr_v[root], -1});
       while (!st.empty()) {
@@ -107,7 +229,7 @@ void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_
           }
           while (fr.up < ptr_t[e + 1]) {
             const int32_t u = ind_t[fr.up++];
-            if (!vis[u] && !is_hub[u]) {
+            if (!vis[u] && !big[u]) {
               vis[u] = 1;
               st.push_back(Frame{u, ptr_v[u], -1});  // invalidates fr
               descended = true;
@@ -184,18 +306,19 @@ void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_
     }
     return next_in_order < order.size() ? order[next_in_order++] : -1;
   };
-  open_panel();
-  for (int32_t v = next_vertex(); v >= 0; v = next_vertex()) {
+  // One panel row: the incidences [p0, p1) of vertex v (all of them, or one piece of a split
+  // vertex), written to `dest` (vertex id, or 0x80000000 | partial slot).
+  auto add_row = [&](int32_t v, int32_t p0, int32_t p1, int32_t dest, bool feed_greedy) {
     int32_t pid = (int32_t)f.panels.size();
     int32_t new_slots = 0, new_mem = 0;
-    for (int32_t p = ptr_v[v]; p < ptr_v[v + 1]; p++) {
+    for (int32_t p = p0; p < p1; p++) {
       const int32_t e = ind_v[p];
       if (stamp[e] != pid) {  // a duplicate incidence is counted twice here; harmless
         new_slots++;
         new_mem += is_mat[e] ? 1 : (ptr_t[e + 1] - ptr_t[e]);
       }
     }
-    const int32_t deg = ptr_v[v + 1] - ptr_v[v];
+    const int32_t deg = p1 - p0;
     const int32_t rows = (int32_t)f.prow.size() - cur.r0;
     const int32_t cur_mem = (int32_t)f.pmem.size() - cur.pm0;
     const int32_t cur_vs = (int32_t)f.pvs.size() - cur.v0;
@@ -206,8 +329,8 @@ void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_
       pid = (int32_t)f.panels.size();
       if (greedy) reset_candidates();
     }
-    if (greedy) done[v] = 1;
-    for (int32_t p = ptr_v[v]; p < ptr_v[v + 1]; p++) {
+    if (greedy && feed_greedy) done[v] = 1;
+    for (int32_t p = p0; p < p1; p++) {
       const int32_t e = ind_v[p];
       if (stamp[e] != pid) {
         stamp[e] = pid;
@@ -218,10 +341,10 @@ void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_
         } else {
           f.pmem.insert(f.pmem.end(), ind_t + ptr_t[e], ind_t + ptr_t[e + 1]);
           f.slot_eid.push_back(e);
-          if (greedy)
+          if (greedy && feed_greedy)
             for (int32_t q = ptr_t[e]; q < ptr_t[e + 1]; q++) {
               const int32_t u = ind_t[q];
-              if (done[u] || is_hub[u]) continue;
+              if (done[u] || big[u]) continue;
               if (score[u]++ == 0) touched.push_back(u);
               heap.push_back(Cand{(float)score[u] / (float)(ptr_v[u + 1] - ptr_v[u]), score[u], u});
               std::push_heap(heap.begin(), heap.end());
@@ -231,12 +354,215 @@ void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_
       }
       f.pvs.push_back((uint16_t)slot_of[e]);
     }
-    f.prow.push_back(v);
+    f.prow.push_back(dest);
     f.pend.push_back((int32_t)f.pvs.size() - cur.v0);
+  };
+  open_panel();
+  for (int32_t v = next_vertex(); v >= 0; v = next_vertex()) add_row(v, ptr_v[v], ptr_v[v + 1], v, true);
+
+  // partial rows: [hub parts x workgroups][pieces][first-level fixup sums]
+  std::vector<Fixup> finals;
+  if (hp.K > 0) build_hub_pass(N, M, ptr_t, ind_t, ptr_v, is_mat, mat_id, hub_of, parts, f.t_big, f, finals);
+  // split vertices: pieces of vdeg_max incidences, each a panel row of its own
+  if (greedy) reset_candidates();
+  for (int32_t v = 0; v < N; v++) {
+    if (big[v] != 2) continue;
+    f.n_split++;
+    const int32_t first = f.n_part;
+    for (int32_t p0 = ptr_v[v]; p0 < ptr_v[v + 1]; p0 += f.vdeg_max) {
+      const int32_t p1 = std::min(p0 + f.vdeg_max, ptr_v[v + 1]);
+      add_row(v, p0, p1, (int32_t)(0x80000000u | (uint32_t)f.n_part), false);
+      f.n_part++;
+    }
+    add_fixups(v, first, f.n_part - first, f.n_part, f.fixups, finals);
   }
   close_panel();
+  f.n_fix_l1 = (int32_t)f.fixups.size();
+  f.fixups.insert(f.fixups.end(), finals.begin(), finals.end());
   f.pmem_entries = (int64_t)f.pmem.size();
   pack_records(f, ng, N);
+}
+
+// Rounds of the hub pass: the hyperedges that contain a register hub, in ascending order, cut
+// into rounds of at most cap slots / mem_cap stream entries / pair_cap (hub, slot) pairs; rounds
+// dealt to the persistent workgroups as contiguous, equally heavy ranges.  Record of one round:
+//   header  : [0] steps  [1] nslots  [2] npairs  [4] off_gbase  [5] off_stream  [6] off_pend
+//             [8] steps_x (materialised slots start here)  [9] off_pvs  [10] off_eid
+//   gbase   : ng words, first slot id of each lane group (as in a panel record)
+//   stream  : steps * ng entry words (as in a panel record; indices below 2^24; the last entry of a slot
+//             carries the slot's heavy-hub mask in bits 24..27)
+//   eid     : nslots hyperedge ids in slot order (-1: materialised, already scaled)
+//   pend    : ng * R 16-bit cumulative end offsets into pvs, one per virtual row (id = group * R + i)
+//   pvs     : npairs 16-bit slot ids, grouped by virtual row, ascending hyperedge inside a row
+static void build_hub_pass(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_t, const int32_t *ptr_v,
+                           const std::vector<uint8_t> &is_mat, const std::vector<int32_t> &mat_id,
+                           const std::vector<int32_t> &hub_of, const std::vector<int32_t> &parts,
+                           int32_t t_big, FusedSched &f, std::vector<Fixup> &finals) {
+  (void)t_big;
+  HubPass &hp = f.hub;
+  const int32_t ng = hp.ng, R = hp.R, idle = N;
+  // virtual rows -> (lane group, register): heaviest first, each to the least loaded group with a free register
+  struct VRow {
+    int32_t hub, part;
+    int64_t w;
+  };
+  std::vector<VRow> vr;
+  for (int32_t h = 0; h < hp.K; h++) {
+    const int64_t d = ptr_v[hp.vid[h] + 1] - ptr_v[hp.vid[h]];
+    for (int32_t j = 0; j < parts[h]; j++) vr.push_back(VRow{h, j, (d + parts[h] - 1) / parts[h]});
+  }
+  std::stable_sort(vr.begin(), vr.end(), [](const VRow &a, const VRow &b) { return a.w > b.w; });
+  std::vector<int64_t> gload((size_t)ng, 0);
+  std::vector<int32_t> gcount((size_t)ng, 0);
+  std::vector<int32_t> part0((size_t)hp.K + 1, 0);  // first index of each hub's parts in vrow_id
+  for (int32_t h = 0; h < hp.K; h++) part0[h + 1] = part0[h] + parts[h];
+  std::vector<int32_t> vrow_id((size_t)part0[hp.K], -1);  // (hub, part) -> group * R + i
+  for (const VRow &x : vr) {
+    int32_t best = -1;
+    for (int32_t g = 0; g < ng; g++)
+      if (gcount[g] < R && (best < 0 || gload[g] < gload[best])) best = g;
+    vrow_id[part0[x.hub] + x.part] = best * R + gcount[best]++;
+    gload[best] += x.w;
+  }
+
+  // rounds
+  std::vector<int32_t> cnt((size_t)hp.K, 0), touched_h;
+  std::vector<int64_t> round_w;
+  struct Slot {
+    int32_t e, m0, m1;  // hyperedge, range in `mem`
+    uint32_t hmask;     // heavy hubs among its members (bit h = hub h)
+  };
+  std::vector<Slot> slots;
+  std::vector<int32_t> mem;                         // stream entry words of the round's slots, unflagged
+  std::vector<std::pair<int32_t, int32_t>> pairs;   // (virtual row, slot index)
+  std::vector<int32_t> eh;                          // hub members of the current hyperedge
+  int32_t longest = 0;                              // longest slot of the open round
+  auto flush = [&]() {
+    if (slots.empty()) return;
+    const int32_t ns = (int32_t)slots.size();
+    std::vector<SlotRange> sr((size_t)ns);
+    for (int32_t k = 0; k < ns; k++) sr[k] = SlotRange{slots[k].m0, slots[k].m1, slots[k].hmask};
+    PackedStream ps;
+    // rows stay below 2^24 wherever the hub pass runs: bits 24..27 of a slot's last entry are its heavy-hub mask
+    pack_stream(sr, mem.data(), ng, idle, f.n_mat, 0x00ffffffu, ps);
+    const int32_t steps = ps.steps;
+    const std::vector<int32_t> &newid = ps.newid, &stream = ps.stream, &gslots = ps.gslots;
+    std::vector<int32_t> eid((size_t)ns, -1);
+    for (int32_t k = 0; k < ns; k++) eid[newid[k]] = is_mat[slots[k].e] ? -1 : slots[k].e;
+    // pairs by virtual row (stable: ascending hyperedge inside a row)
+    std::stable_sort(pairs.begin(), pairs.end(),
+                     [](const std::pair<int32_t, int32_t> &a, const std::pair<int32_t, int32_t> &b) { return a.first < b.first; });
+    const int32_t nvr = ng * R, npairs = (int32_t)pairs.size();
+    const int32_t hdr = 16;
+    const int32_t off_gbase = hdr, off_stream = off_gbase + ng, off_eid = off_stream + steps * ng;
+    const int32_t off_pend = off_eid + ns, off_pvs = off_pend + (nvr + 1) / 2;
+    const int32_t words = (off_pvs + (npairs + 1) / 2 + 3) & ~3;
+    HubRec rt;
+    rt.off = (int64_t)hp.rec.size();
+    rt.len = words;
+    rt.nslots = ns;
+    rt.off_eid = off_eid;
+    rt.pad = 0;
+    hp.rec_tab.push_back(rt);
+    hp.max_rec_words = std::max(hp.max_rec_words, words);
+    hp.max_steps = std::max(hp.max_steps, steps);
+    hp.stream_entries += (int64_t)steps * ng;
+    hp.pairs += npairs;
+    round_w.push_back((int64_t)steps * ng + npairs);
+    const size_t base = hp.rec.size();
+    hp.rec.resize(base + (size_t)words, 0);
+    int32_t *r = hp.rec.data() + base;
+    r[0] = steps;
+    r[1] = ns;
+    r[2] = npairs;
+    r[8] = ps.steps_x;
+    r[4] = off_gbase;
+    r[5] = off_stream;
+    r[6] = off_pend;
+    r[9] = off_pvs;
+    r[10] = off_eid;
+    for (int32_t g = 0; g < ng; g++) r[off_gbase + g] = gslots[g];
+    std::copy(stream.begin(), stream.end(), r + off_stream);
+    std::copy(eid.begin(), eid.end(), r + off_eid);
+    uint16_t *pe = reinterpret_cast<uint16_t *>(r + off_pend);
+    uint16_t *pv = reinterpret_cast<uint16_t *>(r + off_pvs);
+    int32_t q = 0;
+    for (int32_t v = 0; v < nvr; v++) {
+      while (q < npairs && pairs[q].first == v) {
+        pv[q] = (uint16_t)newid[pairs[q].second];
+        q++;
+      }
+      pe[v] = (uint16_t)q;
+    }
+    for (int32_t h : touched_h) cnt[h] = 0;
+    touched_h.clear();
+    slots.clear();
+    mem.clear();
+    pairs.clear();
+  };
+  for (int32_t e = 0; e < M; e++) {
+    eh.clear();
+    for (int32_t p = ptr_t[e]; p < ptr_t[e + 1]; p++)
+      if (hub_of[ind_t[p]] >= 0) eh.push_back(hub_of[ind_t[p]]);
+    if (eh.empty()) continue;
+    const int32_t cost = is_mat[e] ? 1 : ptr_t[e + 1] - ptr_t[e];
+    if (!slots.empty() &&
+        ((int32_t)slots.size() == hp.cap || (int32_t)mem.size() + cost > hp.mem_cap ||
+         (int32_t)pairs.size() + (int32_t)eh.size() > hp.pair_cap ||
+         hub_rec_bound(hp, (int32_t)mem.size() + cost, std::max(longest, cost), (int32_t)slots.size() + 1,
+                       (int32_t)pairs.size() + (int32_t)eh.size()) > kHubRecWords)) {
+      flush();
+      longest = 0;
+    }
+    longest = std::max(longest, cost);
+    const int32_t k = (int32_t)slots.size();
+    const int32_t m0 = (int32_t)mem.size();
+    if (is_mat[e]) mem.push_back((int32_t)(0x80000000u | (uint32_t)mat_id[e]));
+    else mem.insert(mem.end(), ind_t + ptr_t[e], ind_t + ptr_t[e + 1]);
+    uint32_t hmask = 0;
+    for (int32_t h : eh)
+      if (h < hp.n_heavy) hmask |= 1u << h;
+    slots.push_back(Slot{e, m0, (int32_t)mem.size(), hmask});
+    for (int32_t h : eh) {
+      if (h < hp.n_heavy) continue;
+      if (cnt[h] == 0) touched_h.push_back(h);
+      const int32_t part = cnt[h]++ % parts[h];  // a hub's incidences are dealt round-robin to its parts
+      pairs.emplace_back(vrow_id[part0[h] + part], k);
+    }
+  }
+  flush();
+
+  // contiguous, equally heavy round ranges for the persistent workgroups
+  const int32_t nrounds = (int32_t)hp.rec_tab.size();
+  hp.nwg = std::max(1, std::min(256, nrounds));
+  int64_t total = 0;
+  for (int64_t w : round_w) total += w;
+  hp.wg_first.assign((size_t)hp.nwg + 1, nrounds);
+  hp.wg_first[0] = 0;
+  {
+    int64_t acc = 0;
+    int32_t w = 1;
+    for (int32_t r = 0; r < nrounds && w < hp.nwg; r++) {
+      acc += round_w[r];
+      while (w < hp.nwg && acc * hp.nwg >= total * w) hp.wg_first[w++] = r + 1;
+    }
+  }
+  for (int32_t w = 1; w <= hp.nwg; w++) hp.wg_first[w] = std::max(hp.wg_first[w], hp.wg_first[w - 1]);
+  hp.wg_first[hp.nwg] = nrounds;
+
+  // partial slots: hub h owns parts[h] * nwg consecutive rows; fixups add them (rows = vertex ids)
+  hp.vslot0.assign((size_t)ng * R, -1);
+  for (int32_t h = 0; h < hp.n_heavy; h++) {  // one partial row per workgroup
+    hp.hslot0[h] = f.n_part;
+    f.n_part += hp.nwg;
+    add_fixups(hp.vid[h], hp.hslot0[h], hp.nwg, f.n_part, f.fixups, finals);
+  }
+  for (int32_t h = hp.n_heavy; h < hp.K; h++) {
+    const int32_t base = f.n_part;
+    for (int32_t j = 0; j < parts[h]; j++) hp.vslot0[vrow_id[part0[h] + j]] = base + j * hp.nwg;
+    f.n_part += parts[h] * hp.nwg;
+    add_fixups(hp.vid[h], base, parts[h] * hp.nwg, f.n_part, f.fixups, finals);
+  }
 }
 
 // One self-contained int32 record per panel for the packed kernel: a header, the
@@ -244,13 +570,14 @@ void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_
 // the `ng` lane groups with longest-first greedy packing, so every group walks
 // the same number of steps and the loop is wave-uniform), then the hop-2 lists.
 //   header  : [0] steps  [1] nrows  [2] nslots  [3] nvs
-//             [4] off_gbase [5] off_stream [6] off_pend [7] off_prow [9] off_pvs
+//             [4] off_gbase [5] off_stream [6] off_pend [7] off_prow [8] steps_x [9] off_pvs
 //   gbase   : ng words, first slot id of each group (a group's slots are numbered in
 //             the order it finishes them)
-//   stream  : steps * ng words; `idle` (= N, one past the last row of X, no flags) = idle
-//             step, else bits 0..29 row index, bit 30 = row of the materialised table,
-//             bit 31 = last entry of its slot
-//   prow    : nrows vertex ids
+//   stream  : steps * ng words (pack_stream): steps [0, steps_x) hold member rows of X, steps
+//             [steps_x, steps) rows of the materialised table; an idle step names the row one past
+//             the table of its phase (N / n_mat, no flags); else bits 0..29 row index, bit 30 = row
+//             of the materialised table, bit 31 = last entry of its slot
+//   prow    : nrows destinations: vertex id, or 0x80000000 | partial row (a piece of a split vertex)
 //   pend    : nrows local end offsets into pvs, two 16-bit values per word
 //   pvs     : nvs slot ids, two 16-bit values per word
 // The hyperedge id of every slot (-1 = materialised, already scaled) goes to eid_all in
@@ -263,49 +590,17 @@ void pack_records(FusedSched &f, int32_t ng, int32_t idle) {
   f.max_rec_words = 0;
   f.max_steps = 0;
   f.stream_entries = 0;
-  std::vector<int32_t> order, load, gslots, newid, stream;
   for (const FPanel &pn : f.panels) {
     const int32_t *soff = f.soff.data() + pn.sbase;
     const int32_t *pm = f.pmem.data() + pn.pm0;
-    // longest slot first, each to the least loaded group
-    order.resize((size_t)pn.nslots);
-    for (int32_t k = 0; k < pn.nslots; k++) order[k] = k;
-    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
-      return (soff[x + 1] - soff[x]) > (soff[y + 1] - soff[y]);
-    });
-    load.assign((size_t)ng, 0);
-    std::vector<std::vector<int32_t>> members((size_t)ng);
-    for (int32_t k : order) {
-      int32_t best = 0;
-      for (int32_t g = 1; g < ng; g++)
-        if (load[g] < load[best]) best = g;
-      members[best].push_back(k);
-      load[best] += soff[k + 1] - soff[k];
-    }
-    int32_t steps = 0;
-    for (int32_t g = 0; g < ng; g++) steps = std::max(steps, load[g]);
-    // slot ids in (group, completion order); streams
-    newid.assign((size_t)pn.nslots, 0);
-    gslots.assign((size_t)ng, 0);
-    stream.assign((size_t)steps * ng, idle);
-    int32_t next = 0;
+    std::vector<SlotRange> sr((size_t)pn.nslots);
+    for (int32_t k = 0; k < pn.nslots; k++) sr[k] = SlotRange{soff[k], soff[k + 1], 0u};
+    PackedStream ps;
+    pack_stream(sr, pm, ng, idle, f.n_mat, 0x3fffffffu, ps);
+    const int32_t steps = ps.steps;
+    const std::vector<int32_t> &newid = ps.newid, &stream = ps.stream, &gslots = ps.gslots;
     std::vector<int32_t> eid((size_t)pn.nslots);
-    for (int32_t g = 0; g < ng; g++) {
-      gslots[g] = next;
-      int32_t s = 0;
-      for (int32_t k : members[g]) {
-        newid[k] = next;
-        eid[next] = f.slot_eid[pn.eid0 + k];
-        next++;
-        for (int32_t p = soff[k]; p < soff[k + 1]; p++, s++) {
-          uint32_t w = (uint32_t)pm[p];
-          const uint32_t row = w & 0x3fffffffu;
-          const uint32_t mat = (w & 0x80000000u) ? 0x40000000u : 0u;
-          const uint32_t last = (p + 1 == soff[k + 1]) ? 0x80000000u : 0u;
-          stream[(size_t)s * ng + g] = (int32_t)(row | mat | last);
-        }
-      }
-    }
+    for (int32_t k = 0; k < pn.nslots; k++) eid[newid[k]] = f.slot_eid[pn.eid0 + k];
     const int32_t hdr = 16;
     const int32_t off_gbase = hdr, off_stream = off_gbase + ng, off_prow = off_stream + steps * ng;
     const int32_t off_pend = off_prow + pn.nrows, off_pvs = off_pend + (pn.nrows + 1) / 2;
@@ -331,6 +626,7 @@ void pack_records(FusedSched &f, int32_t ng, int32_t idle) {
     r[1] = pn.nrows;
     r[2] = pn.nslots;
     r[3] = pn.nvs;
+    r[8] = ps.steps_x;
     r[4] = off_gbase;
     r[5] = off_stream;
     r[6] = off_pend;

@@ -64,26 +64,75 @@ struct FRec {
   int32_t slot_base, row_base;  // position of this panel's slots / rows in the bound scale arrays
 };
 
+// ---- hub pass (register hubs) -----------------------------------------------
+// The vertices with the most incident hyperedges ("register hubs") are not panel rows: one
+// persistent 1024-thread workgroup per CU keeps a running sum for every one of them in VGPRs
+// (R rows per lane group) while it streams a contiguous range of the hyperedges that contain a
+// hub, in rounds of at most `cap` hyperedge slots: the round's hyperedge sums are computed once
+// into an LDS tile (hop 1 exactly as in a vertex panel), then every lane group adds the tile rows
+// its hubs belong to.  Each workgroup leaves one partial row per virtual row; fixups add them up.
+// A hub with a large share of the incidences is cut into several virtual rows ("parts", its
+// incidences dealt round-robin) so that no lane group becomes the critical path of a round.
+constexpr int kHubRows = 12;   // virtual hub rows per lane group of the hub pass (accumulator registers)
+constexpr int kHubHeavy = 4;  // heavy hubs fed by stream flags: four accumulators per lane (registers are what limits it)
+
+struct HubRec {
+  int64_t off;              // word offset of the round's record
+  int32_t len;              // record length in words (multiple of 4)
+  int32_t nslots, off_eid;  // slots of the round; where their hyperedge ids sit in the record
+  int32_t pad;
+};
+
+struct HubPass {
+  int32_t K = 0;    // register hubs
+  // The first n_heavy of them (the heaviest, at most kHubHeavy) have no virtual rows: a flag bit in the last
+  // stream entry of every hyperedge they belong to (bits 24..29) makes the lane group that finishes
+  // that hyperedge sum add it to a register of its own; the lane groups' registers are added up
+  // once, at the end of the launch.  No tile read, no list entry, perfectly balanced.
+  int32_t n_heavy = 0;
+  int32_t hslot0[kHubHeavy] = {-1, -1, -1, -1};  // first partial row of each heavy hub (+ workgroup id)
+  int32_t nv = 0;   // virtual rows in use (<= ng * R)
+  int32_t bs = 1024, ng = 0, R = kHubRows;
+  int32_t cap = 0, mem_cap = 0, pair_cap = 0;  // per round: slots, stream entries, (row, slot) pairs
+  int32_t nwg = 0;  // persistent workgroups = partial rows per virtual row
+  int32_t max_rec_words = 0, max_steps = 0;
+  int64_t stream_entries = 0;  // row gathers of one hub pass (idle steps included)
+  int64_t pairs = 0;           // hub incidences
+  std::vector<int32_t> vid;     // [K] vertex ids, by degree descending
+  std::vector<int32_t> vslot0;  // [ng * R] first partial slot of each virtual row (+ workgroup id), -1 = unused
+  std::vector<int32_t> rec;     // round records, back to back (see pack_hub_rounds)
+  std::vector<HubRec> rec_tab;  // per round
+  std::vector<int32_t> wg_first;  // [nwg + 1] rounds of each workgroup
+  int32_t *d_vslot0 = nullptr, *d_rec = nullptr, *d_wg_first = nullptr;
+  HubRec *d_rec_tab = nullptr;
+};
+
 struct FusedSched {
   int32_t cap = 0;        // slots per panel (LDS tile rows)
   int32_t rows_cap = 0;   // rows per panel
   int32_t mem_cap = 0;    // staged member entries per panel
   int32_t vslot_cap = 0;  // staged (vertex, slot) incidences per panel
   int32_t t_big = 0;      // hyperedges longer than this are materialised
-  int32_t vdeg_max = 0;   // vertices with more incident hyperedges are "hubs"
-  int32_t n_mat = 0, n_hub = 0;
+  int32_t vdeg_max = 0;   // vertices with more incident hyperedges are hubs or cut into pieces
+  int32_t n_mat = 0;
+  int32_t n_split = 0;    // vertices cut into pieces (panel rows that write partial sums)
   std::vector<FPanel> panels;
   std::vector<int32_t> soff, pmem, slot_eid;
-  std::vector<int32_t> prow, pend;  // panel rows (vertex ids) and their local end offsets
+  // panel rows: vertex id, or 0x80000000 | partial slot for a piece of a split vertex
+  std::vector<int32_t> prow, pend;
   std::vector<uint16_t> pvs;        // panel-ordered incidences: local slot ids
-  // materialised hyperedges (compact CSR over their members) and hub vertices
-  // (compact CSR over their materialised hyperedges)
-  std::vector<int32_t> mat_ptr, mat_ind, mat_eid, hub_ptr, hub_ind, hub_vid;
-  Sched mat_sched, hub_sched;
+  // materialised hyperedges (compact CSR over their members)
+  std::vector<int32_t> mat_ptr, mat_ind, mat_eid;
+  Sched mat_sched;
+  HubPass hub;
+  // partial rows of the fused path: [hub: sum over hubs of parts * nwg][pieces][first-level sums]
+  int32_t n_part = 0;
+  std::vector<Fixup> fixups;  // rows = vertex ids (hubs and split vertices); first-level ones first
+  int32_t n_fix_l1 = 0;
+  Fixup *d_fixups = nullptr;
   // device copies (the panel lists above stay on the host: the kernel reads the packed records)
   int32_t *d_prow = nullptr;
   int32_t *d_mat_ptr = nullptr, *d_mat_ind = nullptr, *d_mat_eid = nullptr;
-  int32_t *d_hub_ptr = nullptr, *d_hub_ind = nullptr, *d_hub_vid = nullptr;
   int64_t pmem_entries = 0;
   // packed per-panel records (see pack_records in hg_fused.cpp)
   int32_t ng = 0;             // lane groups the hop-1 stream is packed for
@@ -111,6 +160,11 @@ struct Opts {
   int32_t flags = 0;
   int32_t t_big = 8;           // fused: recompute hyperedges of at most this many members
   int32_t fused_tile_bytes = 16384;  // fused: LDS tile budget -> hyperedge slots per panel
+  int32_t fused_steps = 0;           // fused: stream entries per lane group and panel (0: 4 per slot on average)
+  // hub pass (not in the C ABI; the host tests lower them to reach that code on small graphs)
+  int64_t hub_min_nnz = 1 << 20;  // smaller graphs are launch-bound: no extra pass
+  int32_t hub_min_deg = 256;      // below this a hub's partial rows cost more than pieces do
+  int32_t hub_tile_bytes = 80 * 1024;  // LDS tile of a hub-pass round (of the CU's 160 KiB; the rest: two records, scales)
 };
 
 void set_error(const std::string &msg);
@@ -126,10 +180,15 @@ void transpose_csr(int32_t nrows, int32_t ncols, const int32_t *ptr,
                    std::vector<int32_t> &t_ind);
 void build_sched(int32_t nrows, const int32_t *ptr, const Opts &o, Sched &s);
 void classify_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ptr_v, const int32_t *ind_v,
-                    const Opts &o, int32_t cap, int32_t mem_cap, int64_t *n_mat, int64_t *n_hub);
+                    const Opts &o, int32_t cap, int32_t mem_cap, int64_t *n_mat, int64_t *n_big);
+// row_floats: floats per LDS tile row (the kernels' TW); allow_hub: the hub pass may be used
+// (buffer-addressable tables).
 void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_t,
                  const int32_t *ptr_v, const int32_t *ind_v, const Opts &o, int32_t cap,
-                 int32_t mem_cap, int32_t ng, FusedSched &f);
+                 int32_t mem_cap, int32_t ng, int32_t row_floats, bool allow_hub, FusedSched &f);
+// the two-level fixup rule shared by build_sched and build_fused
+void add_fixups(int32_t row, int32_t first, int32_t count, int32_t &nslots, std::vector<Fixup> &level1,
+                std::vector<Fixup> &finals);
 
 }  // namespace hg
 
@@ -142,6 +201,7 @@ struct hg_plan {
   int32_t *d_ptr_v = nullptr, *d_ind_v = nullptr;
   hg::Sched sched[2];  // [0]: H_T rows = hyperedges, [1]: H rows = vertices
   std::map<int64_t, hg::FusedSched> fused;  // keyed by (slot, entry) capacity: depends on F
+  std::map<int64_t, const hg::FusedSched *> fused_by_width;  // (F, vec4) -> the schedule built for it
   std::mutex fused_mu;
   std::map<int64_t, int32_t> auto_choice;  // what HG_VARIANT_AUTO resolved to, keyed by (F, vec4)
   std::mutex auto_mu;

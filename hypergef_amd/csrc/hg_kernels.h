@@ -49,11 +49,13 @@ struct FusedArgs {
   const float *X, *Xe_mat, *degE, *W, *degV;
   const float *bsA, *bsB, *bsD;  // bound scales in panel order (or null: gather from degE/W/degV)
   float *Y;
+  float *partial = nullptr;  // partial rows (pieces of split vertices): a row id with bit 31 set lands here
   int32_t F;
   int32_t xcd_remap;
   int32_t x_bytes;        // byte size of X if it fits a buffer descriptor (< 2 GiB), else 0
   int32_t mat_bytes;      // same for the materialised table
   int32_t nrows_x;        // rows of X
+  int32_t nrows_mat = 0;  // rows of the materialised table
   int32_t debug = 0;      // ablation / stamp bits (experiments only)
   // fused linear epilogue (hg_aggr_linear_f32): Y[N, F_out] = (aggregated rows) * Wlin^T
   const float *Wlin = nullptr;  // Wlin [F_out, F] in MFMA fragment order (launch_linear_pack), or null
@@ -72,6 +74,22 @@ struct LinearArgs {
   LinEpilogue epi;
 };
 
+// The hub pass (HubPass, hg_internal.h): persistent workgroups, register accumulators.
+struct HubArgs {
+  const int32_t *rec;       // round records (hg_fused.cpp, build_hub_pass)
+  const HubRec *rec_tab;
+  const int32_t *wg_first;  // [nwg + 1] rounds of each workgroup
+  const int32_t *vslot0;    // [ng * R] first partial row of each virtual row, -1 = unused
+  int32_t nwg, ng, cap, max_rec_words;
+  const float *X, *Xe_mat, *degE, *W;
+  float *partial;
+  int32_t F;
+  int32_t x_bytes, mat_bytes, nrows_x, nrows_mat;
+  int32_t n_heavy = 0;  // hubs fed by stream flags (bits 24..27 of a slot's last entry)
+  int32_t hslot0[kHubHeavy] = {-1, -1, -1, -1};  // their first partial rows
+  int32_t debug = 0;    // ablation bits, diagnostic build only
+};
+
 struct PushArgs {
   int64_t n_group;
   const int32_t *group_key, *group_row, *group_st, *group_ed;
@@ -84,6 +102,11 @@ struct PushArgs {
 hipError_t launch_gather(const GatherArgs &a, int nfix, int nfix_l1, const Fixup *fixups, bool vec4,
                          hipStream_t stream);
 hipError_t launch_fused(const FusedArgs &a, bool vec4, hipStream_t stream);
+hipError_t launch_hub_pass(const HubArgs &a, bool vec4, hipStream_t stream);
+size_t hub_pass_lds_bytes(int32_t cap, int32_t row_floats, int32_t max_rec_words);
+// Y[fx.row] = scale[fx.row] * (sum of the fixup's partial rows); first-level fixups first
+hipError_t launch_fixups(const Fixup *fixups, int nfix, int nfix_l1, int32_t F, float *partial, float *Y,
+                         const float *scale, bool vec4, hipStream_t stream);
 bool fused_linear_ok(const FusedArgs &a);  // can launch_fused run this call's linear epilogue?
 hipError_t launch_linear(const LinearArgs &a, hipStream_t stream);
 int wgrad_parts(int64_t nrows, int32_t Fa, int32_t Fb);

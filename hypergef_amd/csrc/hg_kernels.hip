@@ -677,8 +677,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LIN ? (LPR 
       }
     }
   if (a.degV)
-    for (int i = tid; i < rt.nrows; i += BS)
-      sdeg[i] = a.bsD ? a.bsD[rt.row_base + i] : a.degV[grec[rt.off_prow + i]];
+    for (int i = tid; i < rt.nrows; i += BS) {
+      if (a.bsD) {
+        sdeg[i] = a.bsD[rt.row_base + i];
+      } else {
+        const int pr = grec[rt.off_prow + i];  // bit 31: a piece of a split vertex, scaled by its fixup
+        sdeg[i] = pr < 0 ? 1.f : a.degV[pr];
+      }
+    }
   HG_STAMP(1);
   __syncthreads();
   HG_STAMP(2);
@@ -708,33 +714,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LIN ? (LPR 
       rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.Xe_mat ? a.Xe_mat : a.X), 0,
                                              (a.Xe_mat && !no_x) ? a.mat_bytes : 0, 0x00020000);
     }
-    const int idle = a.nrows_x;
-    // FULL: all U steps of the block exist, so the entry reads need no bounds test.
-    auto block = [&](const int s0, auto full) {
+    // The stream has two phases (pack_stream, hg_fused.cpp): steps [0, steps_x) gather member rows of X,
+    // steps [steps_x, steps) rows of the materialised table -- one buffer descriptor per phase, no
+    // per-entry test.  FULL: all U steps of the block exist, so the entry reads need no bounds test.
+    auto block = [&](const int s0, const int send, auto full, auto matph) {
       constexpr bool FULL = decltype(full)::value;
+      constexpr bool MATPH = decltype(matph)::value;
+      const int idle = MATPH ? a.nrows_mat : a.nrows_x;
       int ent[U];
 #pragma unroll
-      for (int j = 0; j < U; j++) ent[j] = (FULL || s0 + j < steps) ? stream[(s0 + j) * NG + g] : idle;
+      for (int j = 0; j < U; j++) ent[j] = (FULL || s0 + j < send) ? stream[(s0 + j) * NG + g] : idle;
       V v[U];
 #pragma unroll
       for (int j = 0; j < U; j++) {
-        if (!FULL && s0 + j >= steps) {  // wave-uniform: no load is issued for a step that is not there
+        if (!FULL && s0 + j >= send) {  // wave-uniform: no load is issued for a step that is not there
           v[j] = V::zero();
           continue;
         }
         if constexpr (FAST) {
           const unsigned off = __umul24((unsigned)ent[j], row_bytes) + col_off;  // flags sit above bit 23
-          if constexpr (MAT) {
-            const bool mat = (ent[j] & 0x40000000) != 0;
-            v[j] = V::load_buf(rx, mat ? 0x80000000u : off);
-            if (mat) v[j] = V::load_buf(rm, off);
-          } else {
-            v[j] = V::load_buf(rx, off);
-          }
+          v[j] = V::load_buf(MATPH ? rm : rx, off);
         } else {
           const bool on = col_ok && ent[j] != idle && !(DBG && (a.debug & 1));
           const int64_t idx = ent[j] & 0x3fffffff;
-          const float *base = (MAT && a.Xe_mat && (ent[j] & 0x40000000)) ? a.Xe_mat : a.X;
+          const float *base = MATPH ? a.Xe_mat : a.X;
           v[j] = on ? V::load(base + idx * F + col) : V::zero();
         }
       }
@@ -753,9 +756,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LIN ? (LPR 
         }
       }
     };
+    const int steps_x = MAT ? rec[8] : steps;
     int s0 = 0;
-    for (; s0 + U <= steps; s0 += U) block(s0, std::true_type{});
-    if (s0 < steps) block(s0, std::false_type{});
+    for (; s0 + U <= steps_x; s0 += U) block(s0, steps_x, std::true_type{}, std::false_type{});
+    if (s0 < steps_x) block(s0, steps_x, std::false_type{}, std::false_type{});
+    if constexpr (MAT) {
+      for (s0 = steps_x; s0 + U <= steps; s0 += U) block(s0, steps, std::true_type{}, std::true_type{});
+      if (s0 < steps) block(s0, steps, std::false_type{}, std::true_type{});
+    }
   }
   HG_STAMP(3);
   __syncthreads();
@@ -823,14 +831,227 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LIN ? (LPR 
       for (int p = pb; p < pe; p++) acc.add(V::load(tile + (int)pvs[p] * TW + lcol));
       if (a.degV && pe > pb) acc.mul(sdeg[r]);
       if (col_ok && !(DBG && (a.debug & 2))) {
-        if (DBG && (a.debug & 64)) acc.store_nt(a.Y + (int64_t)prow[r] * F + col);
-        else acc.store(a.Y + (int64_t)prow[r] * F + col);
+        const int pr = prow[r];  // vertex id, or bit 31 | partial row (a piece of a split vertex)
+        float *dst = (pr < 0 ? a.partial + (int64_t)(pr & 0x7fffffff) * F : a.Y + (int64_t)pr * F) + col;
+        if (DBG && (a.debug & 64)) acc.store_nt(dst);
+        else acc.store(dst);
       }
     }
   }
   HG_STAMP(5);
 }
 
+
+// The hub pass (HubPass, hg_internal.h).  One persistent 1024-thread workgroup per CU: lane group g
+// keeps the running sums of its R virtual hub rows in registers for the whole launch and walks the
+// workgroup's rounds; per round the hyperedge sums are computed ONCE into the LDS tile (hop 1 as in
+// fused_packed_kernel: same entry words, same unpredicated buffer loads) and every lane group adds
+// the tile rows its hubs belong to (16-bit lists, cumulative ends per virtual row).  A vertex in
+// 10^6 hyperedges costs one LDS row read per incidence instead of one 4F-byte row of a 1 GB table
+// from HBM, and the table never exists.  Each workgroup writes one partial row per virtual row;
+// fixup_rows_kernel adds them in slot order.
+//  * The next round's record travels through registers during hop 1 (two dwordx4 per thread), so
+//    its round trip hides behind the row gathers.
+//  * HEAVY: the (at most six) heaviest hubs have no virtual rows.  Bits 24..29 of the last entry of a
+//    slot name the heavy hubs among the hyperedge's members, and the lane group that finishes the sum
+//    adds it to registers of its own: no tile read, no list entry, every lane group equally loaded.
+//    The lane groups' registers are added up once, at the end (through the tile, in group order).
+//  * Hop 2 is latency-bound (index read -> tile row read -> add, ~2 LDS latencies per pair on one
+//    dependent chain): the lane group's R ends are fetched at once, and the rows are walked four
+//    registers at a time, all four pairs of a step in flight; a step past a row's end reads the
+//    all-zero row `cap` instead of branching.  Registers are ordered by weight (the plan deals the
+//    heaviest rows first), so the four rows of a chunk have similar lengths.
+#ifdef HG_TUNING
+#define HG_HUB_ABLATE(bit) ((a.debug & (bit)) != 0)  // diagnostic build: HG_HUB_DEBUG, 1 = no hop 1, 2 = no hop 2, 4 = no memory
+#else
+#define HG_HUB_ABLATE(bit) false
+#endif
+template <int LPR, int VEC, int U, bool MAT, bool SCALED, bool HEAVY>
+__global__ __launch_bounds__(1024) void hub_pass_kernel(const HubArgs a) {
+  constexpr int BS = 1024, NG = BS / LPR, TW = LPR * VEC, R = kHubRows, NH = HEAVY ? kHubHeavy : 1;
+  using V = Vec<VEC>;
+  extern __shared__ int32_t smem[];
+  const int tid = threadIdx.x;
+  const int gl = tid & (LPR - 1);
+  const int lcol = gl * VEC;
+  const int col = blockIdx.y * TW + lcol;
+  const bool col_ok = col < a.F;
+  const int64_t F = a.F;
+  const int w = blockIdx.x;
+  const int g = tid / LPR;
+  float *tile = reinterpret_cast<float *>(smem);                          // [(cap + 1) * TW], row `cap` = zeros
+  int32_t *recbuf = smem + (a.cap + 1) * TW;                              // 2 x [max_rec_words]: this round's record, the next one's
+  float *sA = reinterpret_cast<float *>(recbuf + 2 * a.max_rec_words);    // [cap]
+  float *sB = sA + a.cap;                                                 // [cap]
+
+  V acc[R];
+#pragma unroll
+  for (int i = 0; i < R; i++) acc[i] = V::zero();
+  [[maybe_unused]] V hacc[NH];
+#pragma unroll
+  for (int h = 0; h < NH; h++) hacc[h] = V::zero();
+  if (tid < LPR) V::zero().store(tile + a.cap * TW + lcol);
+  const unsigned row_bytes = (unsigned)a.F * 4u;
+  const unsigned col_off = col_ok ? (unsigned)col * 4u : 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.X), 0, HG_HUB_ABLATE(4) ? 0 : a.x_bytes, 0x00020000);
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(a.Xe_mat ? a.Xe_mat : a.X), 0, (a.Xe_mat && !HG_HUB_ABLATE(4)) ? a.mat_bytes : 0, 0x00020000);
+  const int rd0 = a.wg_first[w], rd1 = a.wg_first[w + 1];
+  // A record is at most NPRE * 16 KB: each thread carries NPRE dwordx4 of the NEXT round's record
+  // through hop 1, so the copy's round trip hides behind the row gathers.
+  constexpr int NPRE = 2;
+  hg_i4 pre[NPRE];
+  auto fetch = [&](int rd) {
+    const HubRec rt = a.rec_tab[rd];
+    const hg_i4 *src = reinterpret_cast<const hg_i4 *>(a.rec + rt.off);
+#pragma unroll
+    for (int k = 0; k < NPRE; k++) {
+      const int i = tid + k * BS;
+      if (i < (rt.len >> 2)) pre[k] = src[i];
+    }
+    return rt.len >> 2;
+  };
+  auto stash = [&](int32_t *dst, int n4) {
+#pragma unroll
+    for (int k = 0; k < NPRE; k++) {
+      const int i = tid + k * BS;
+      if (i < n4) reinterpret_cast<hg_i4 *>(dst)[i] = pre[k];
+    }
+  };
+  int cur = 0;
+  if (rd0 < rd1) stash(recbuf, fetch(rd0));
+  __syncthreads();
+  for (int rd = rd0; rd < rd1; rd++) {
+    const int32_t *rec = recbuf + cur * a.max_rec_words;
+    int n4_next = 0;
+    if (rd + 1 < rd1) n4_next = fetch(rd + 1);  // in flight across hop 1
+    if constexpr (SCALED) {
+      const int nslots = rec[1];
+      const int32_t *eid = rec + rec[10];
+      for (int i = tid; i < nslots; i += BS) {
+        const int e = eid[i];  // -1: materialised row, already scaled
+        sA[i] = (a.degE && e >= 0) ? a.degE[e] : 1.f;
+        sB[i] = (a.W && e >= 0) ? a.W[e] : 1.f;
+      }
+      __syncthreads();
+    }
+    const int steps = rec[0];
+    const int32_t *gbase = rec + rec[4];
+    const int32_t *stream = rec + rec[5];
+    const uint16_t *pend = reinterpret_cast<const uint16_t *>(rec + rec[6]);
+    const uint16_t *pvs = reinterpret_cast<const uint16_t *>(rec + rec[9]);
+    if (!HG_HUB_ABLATE(1)) {  // ---- hop 1: this round's hyperedge sums -> tile (and heavy hubs' registers)
+      [[maybe_unused]] int slot = gbase[g];
+      float *tp = tile + gbase[g] * TW + lcol;
+      V sum = V::zero();
+      // two phases, as in fused_packed_kernel: rows of X, then rows of the materialised table
+      auto block = [&](const int s0, const int send, auto full, auto matph) {
+        constexpr bool FULL = decltype(full)::value;
+        constexpr bool MATPH = decltype(matph)::value;
+        const int idle = MATPH ? a.nrows_mat : a.nrows_x;
+        int ent[U];
+#pragma unroll
+        for (int j = 0; j < U; j++) ent[j] = (FULL || s0 + j < send) ? stream[(s0 + j) * NG + g] : idle;
+        V v[U];
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+          if (!FULL && s0 + j >= send) {
+            v[j] = V::zero();
+            continue;
+          }
+          const unsigned off = __umul24((unsigned)ent[j], row_bytes) + col_off;  // flags sit above bit 23
+          v[j] = V::load_buf(MATPH ? rm : rx, off);
+        }
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+          sum.add(v[j]);
+          if (ent[j] < 0) {  // bit 31: last member of this slot
+            if constexpr (SCALED) {
+              if (a.degE) sum.mul(sA[slot]);
+              if (a.W) sum.mul(sB[slot]);
+              slot++;
+            }
+            sum.store(tp);
+            tp += TW;
+            if constexpr (HEAVY) {
+              const int hm = (ent[j] >> 24) & ((1 << NH) - 1);
+              if (hm) {
+#pragma unroll
+                for (int h = 0; h < NH; h++)
+                  if (hm & (1 << h)) hacc[h].add(sum);
+              }
+            }
+            sum = V::zero();
+          }
+        }
+      };
+      const int steps_x = MAT ? rec[8] : steps;
+      int s0 = 0;
+      for (; s0 + U <= steps_x; s0 += U) block(s0, steps_x, std::true_type{}, std::false_type{});
+      if (s0 < steps_x) block(s0, steps_x, std::false_type{}, std::false_type{});
+      if constexpr (MAT) {
+        for (s0 = steps_x; s0 + U <= steps; s0 += U) block(s0, steps, std::true_type{}, std::true_type{});
+        if (s0 < steps) block(s0, steps, std::false_type{}, std::true_type{});
+      }
+    }
+    stash(recbuf + (cur ^ 1) * a.max_rec_words, n4_next);  // nobody reads that buffer during this round
+    __syncthreads();
+    // ---- hop 2: every virtual row adds the tile rows of the hyperedges it belongs to
+    if (!HG_HUB_ABLATE(2)) {
+      // the lane group's R cumulative ends: eight aligned dwords of 16-bit pairs (g * R is a multiple of 16)
+      const uint32_t *pw = reinterpret_cast<const uint32_t *>(pend) + g * (R / 2);
+      uint32_t ew[R / 2];
+#pragma unroll
+      for (int i = 0; i < R / 2; i++) ew[i] = pw[i];
+      const int first = g ? (int)(pw[-1] >> 16) : 0;
+      auto end_of = [&](int i) { return (int)((ew[i >> 1] >> ((i & 1) * 16)) & 0xffffu); };  // i static
+      constexpr int C = 4;  // rows walked together: four (index, tile row) pairs in flight per lane group
+#pragma unroll
+      for (int c = 0; c < R; c += C) {
+        int b_[C], n_[C], len = 0;
+#pragma unroll
+        for (int i = 0; i < C; i++) {
+          b_[i] = c + i ? end_of(c + i - 1) : first;
+          n_[i] = end_of(c + i) - b_[i];
+          len = max(len, n_[i]);
+        }
+        for (int k = 0; __builtin_amdgcn_ballot_w64(k < len) != 0; k++) {  // wave-uniform trip count
+          int sidx[C];
+#pragma unroll
+          for (int i = 0; i < C; i++) sidx[i] = k < n_[i] ? (int)pvs[b_[i] + k] : a.cap;
+          V t[C];
+#pragma unroll
+          for (int i = 0; i < C; i++) t[i] = V::load(tile + sidx[i] * TW + lcol);
+#pragma unroll
+          for (int i = 0; i < C; i++) acc[c + i].add(t[i]);
+        }
+      }
+    }
+    __syncthreads();  // the tile is rewritten by the next round, this record by the one after
+    cur ^= 1;
+  }
+#pragma unroll
+  for (int i = 0; i < R; i++) {
+    const int s0 = a.vslot0[g * R + i];
+    if (s0 >= 0 && col_ok) acc[i].store(a.partial + (int64_t)(s0 + w) * F + col);
+  }
+  if constexpr (HEAVY) {  // the lane groups' shares of each heavy hub, added in group order
+    for (int h = 0; h < a.n_heavy; h++) {
+      V mine = V::zero();
+#pragma unroll
+      for (int q = 0; q < NH; q++)
+        if (q == h) mine = hacc[q];
+      mine.store(tile + g * TW + lcol);
+      __syncthreads();
+      if (g == 0) {
+        V tot = V::zero();
+        for (int q = 0; q < NG; q++) tot.add(V::load(tile + q * TW + lcol));
+        if (col_ok) tot.store(a.partial + (int64_t)(a.hslot0[h] + w) * F + col);
+      }
+      __syncthreads();
+    }
+  }
+}
 
 // The reference's register-fused scheme on wave64: LPR lanes = LPR feature
 // columns of one task, 64/LPR tasks per wave.  Gather-sum the read partition,
@@ -868,6 +1089,8 @@ __global__ __launch_bounds__(256) void push_groups_kernel(const PushArgs a) {
     atomicAdd(a.Y + v * F + k, acc * degV_val);
   }
 }
+
+int fused_tile_row_floats(int F, bool vec4);
 
 static inline int next_pow2(int x) {
   int p = 1;
@@ -912,7 +1135,7 @@ constexpr bool kDbgFallback = true;   // diagnostic build: ablation switches sta
 #else
 constexpr bool kDbgFallback = false;
 #endif
-template <auto Kern, typename Args>
+template <auto Kern, int BLOCK = 256, typename Args>
 static hipError_t launch_lds(dim3 grid, size_t lds, hipStream_t stream, const Args &a) {
   static std::atomic<size_t> granted{64 * 1024};
   if (lds > kLdsMax) return hipErrorInvalidValue;
@@ -922,7 +1145,21 @@ static hipError_t launch_lds(dim3 grid, size_t lds, hipStream_t stream, const Ar
     if (e != hipSuccess) return e;
     granted.store(kLdsMax, std::memory_order_relaxed);
   }
-  hipLaunchKernelGGL(Kern, grid, dim3(256), lds, stream, a);
+  hipLaunchKernelGGL(Kern, grid, dim3(BLOCK), lds, stream, a);
+  return hipGetLastError();
+}
+
+template <int LPR, int VEC>
+static hipError_t launch_fixups_t(const GatherArgs &a, int nfix, int nfix_l1, const Fixup *fixups, hipStream_t stream) {
+  const int col_tiles = (a.F + LPR * VEC - 1) / (LPR * VEC);
+  const int per_block = 256 / LPR;
+  if (nfix_l1 > 0)  // first level of the two-level sums (rows cut into very many tasks)
+    hipLaunchKernelGGL((fixup_rows_kernel<LPR, VEC>), dim3((nfix_l1 + per_block - 1) / per_block, col_tiles),
+                       dim3(256), 0, stream, a, fixups, nfix_l1);
+  if (nfix > nfix_l1)
+    hipLaunchKernelGGL((fixup_rows_kernel<LPR, VEC>),
+                       dim3((nfix - nfix_l1 + per_block - 1) / per_block, col_tiles), dim3(256), 0, stream, a,
+                       fixups + nfix_l1, nfix - nfix_l1);
   return hipGetLastError();
 }
 
@@ -945,15 +1182,7 @@ static hipError_t launch_gather_t(const GatherArgs &a, int nfix, int nfix_l1, co
     }
     if (e != hipSuccess) return e;
   }
-  const int per_block = 256 / LPR;
-  if (nfix_l1 > 0)  // first level of the two-level sums (rows cut into very many tasks)
-    hipLaunchKernelGGL((fixup_rows_kernel<LPR, VEC>), dim3((nfix_l1 + per_block - 1) / per_block, col_tiles),
-                       dim3(256), 0, stream, a, fixups, nfix_l1);
-  if (nfix > nfix_l1)
-    hipLaunchKernelGGL((fixup_rows_kernel<LPR, VEC>),
-                       dim3((nfix - nfix_l1 + per_block - 1) / per_block, col_tiles), dim3(256), 0, stream, a,
-                       fixups + nfix_l1, nfix - nfix_l1);
-  return hipGetLastError();
+  return launch_fixups_t<LPR, VEC>(a, nfix, nfix_l1, fixups, stream);
 }
 
 hipError_t launch_gather(const GatherArgs &a, int nfix, int nfix_l1, const Fixup *fixups, bool vec4,
@@ -977,6 +1206,79 @@ hipError_t launch_gather(const GatherArgs &a, int nfix, int nfix_l1, const Fixup
   return hipErrorInvalidValue;
 }
 
+hipError_t launch_fixups(const Fixup *fixups, int nfix, int nfix_l1, int32_t F, float *partial, float *Y,
+                         const float *scale, bool vec4, hipStream_t stream) {
+  if (nfix == 0) return hipSuccess;
+  GatherArgs a{};
+  a.F = F;
+  a.partial = partial;
+  a.dst = Y;
+  a.scaleA = scale;
+  const int lanes = vec4 ? F / 4 : F;
+  const int lpr = std::min(64, next_pow2(std::max(lanes, 1)));
+#define HG_CASE(L) \
+  case L:          \
+    return vec4 ? launch_fixups_t<L, 4>(a, nfix, nfix_l1, fixups, stream) : launch_fixups_t<L, 1>(a, nfix, nfix_l1, fixups, stream);
+  switch (lpr) {
+    HG_CASE(1)
+    HG_CASE(2)
+    HG_CASE(4)
+    HG_CASE(8)
+    HG_CASE(16)
+    HG_CASE(32)
+    HG_CASE(64)
+  }
+#undef HG_CASE
+  return hipErrorInvalidValue;
+}
+
+size_t hub_pass_lds_bytes(int32_t cap, int32_t row_floats, int32_t max_rec_words) {
+  return (size_t)(cap + 1) * row_floats * 4 + (size_t)2 * max_rec_words * 4 + (size_t)2 * cap * 4 + 16;
+}
+
+template <int LPR>
+static hipError_t launch_hub_t(const HubArgs &a, hipStream_t stream) {
+  constexpr int TW = LPR * 4;
+  if (a.ng != 1024 / LPR) return hipErrorInvalidValue;  // records were packed for another lane layout
+  const bool fast = a.x_bytes > 0 && a.nrows_x < (1 << 24) && a.F < (1 << 22) &&
+                    (!a.Xe_mat || (a.mat_bytes > 0 && a.nrows_mat < (1 << 24)));
+  if (!fast) return hipErrorInvalidValue;  // the plan builds a hub pass only for buffer-addressable tables
+  const dim3 grid(a.nwg, (a.F + TW - 1) / TW);
+  const size_t lds = hub_pass_lds_bytes(a.cap, TW, a.max_rec_words);
+  if (a.cap < 1024 / LPR) return hipErrorInvalidValue;  // the end-of-launch reduction parks one row per lane group in the tile
+  const int spec = (a.Xe_mat ? 1 : 0) | ((a.degE || a.W) ? 2 : 0) | (a.n_heavy > 0 ? 4 : 0);
+#define HG_HUB(M, S, H) return launch_lds<hub_pass_kernel<LPR, 4, 4, M, S, H>, 1024>(grid, lds, stream, a)
+  switch (spec) {
+    case 0: HG_HUB(false, false, false);
+    case 1: HG_HUB(true, false, false);
+    case 2: HG_HUB(false, true, false);
+    case 3: HG_HUB(true, true, false);
+    case 4: HG_HUB(false, false, true);
+    case 5: HG_HUB(true, false, true);
+    case 6: HG_HUB(false, true, true);
+    default: HG_HUB(true, true, true);
+  }
+#undef HG_HUB
+}
+
+hipError_t launch_hub_pass(const HubArgs &a0, bool vec4, hipStream_t stream) {
+  HubArgs a = a0;
+#ifdef HG_TUNING
+  if (const char *e = getenv("HG_HUB_DEBUG")) a.debug = atoi(e);  // ablation: 1 = no hop 1, 2 = no hop 2
+#endif
+  if (a.nwg == 0) return hipSuccess;
+  if (!vec4) return hipErrorInvalidValue;
+  const int lpr = fused_tile_row_floats(a.F, true) / 4;
+  switch (lpr) {
+    case 4: return launch_hub_t<4>(a, stream);
+    case 8: return launch_hub_t<8>(a, stream);
+    case 16: return launch_hub_t<16>(a, stream);
+    case 32: return launch_hub_t<32>(a, stream);
+    case 64: return launch_hub_t<64>(a, stream);
+  }
+  return hipErrorInvalidValue;
+}
+
 template <int LPR, int VEC>
 static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
   if (a.npanels == 0) return hipSuccess;
@@ -993,7 +1295,7 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
                        (size_t)(((a.degE || a.W) ? 2 * a.cap : 0) + (a.degV ? a.rows_cap : 0)) * 4 + 16;
   if constexpr (VEC == 4) {
     const bool fast = t.fused_fast && a.x_bytes > 0 && a.nrows_x < (1 << 24) && a.F < (1 << 22) &&
-                      (!a.Xe_mat || a.mat_bytes > 0);
+                      (!a.Xe_mat || (a.mat_bytes > 0 && a.nrows_mat < (1 << 24)));
     if (a.Wlin) {  // linear epilogue: eligibility was checked by fused_linear_ok
       if constexpr (TW == 32 || TW == 64 || TW == 128) {
         if (!fast || a.F != TW || a.rows_cap > 4 * (256 / LPR) || (a.F_out & 15)) return hipErrorInvalidValue;
@@ -1045,7 +1347,7 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
   if constexpr (VEC == 1 && LPR >= 8) {  // F >= 5, not a multiple of 4 (class-count widths): the same buffer-load
                                           // loop, one dword per lane (+7-20 % at F = 7, 33; narrower rows: no gain)
     const bool fast = t.fused_fast && !t.fused_debug && a.x_bytes > 0 && a.nrows_x < (1 << 24) && a.F < (1 << 22) &&
-                      (!a.Xe_mat || a.mat_bytes > 0);
+                      (!a.Xe_mat || (a.mat_bytes > 0 && a.nrows_mat < (1 << 24)));
     if (fast) {
       if (!a.Xe_mat && !a.degE && !a.W)
         return launch_lds<fused_packed_kernel<LPR, VEC, 8, true, false, false, false>>(grid, lds_p, stream, ad);
@@ -1103,7 +1405,8 @@ bool fused_linear_ok(const FusedArgs &a) {
   const Tuning &t = tuning();
   const int lpr = a.F / 4;
   return (a.F == 32 || a.F == 64 || a.F == 128) && a.F_out > 0 && (a.F_out & 15) == 0 && t.fused_fast &&
-         !(t.fused_debug & 255) && a.x_bytes > 0 && a.nrows_x < (1 << 24) && (!a.Xe_mat || a.mat_bytes > 0) &&
+         !(t.fused_debug & 255) && a.x_bytes > 0 && a.nrows_x < (1 << 24) &&
+         (!a.Xe_mat || (a.mat_bytes > 0 && a.nrows_mat < (1 << 24))) &&
          a.ng == 256 / lpr && a.rows_cap <= 4 * (256 / lpr) && a.rows_cap == a.cap;
 }
 
@@ -1239,7 +1542,7 @@ __global__ __launch_bounds__(256) void bind_scales_kernel(int64_t nslots, const 
     bsA[t] = (degE && e >= 0) ? degE[e] : 1.f;
     bsB[t] = (W && e >= 0) ? W[e] : 1.f;
   }
-  if (t < nrows) bsD[t] = degV ? degV[prow[t]] : 1.f;
+  if (t < nrows) bsD[t] = (degV && prow[t] >= 0) ? degV[prow[t]] : 1.f;  // pieces of split vertices: scaled by their fixup
 }
 
 hipError_t launch_bind_scales(int64_t nslots, const int32_t *eid_all, const float *degE, const float *W,

@@ -129,6 +129,23 @@ void transpose_csr(int32_t nrows, int32_t ncols, const int32_t *ptr,
 //    slots into a slot of its own (Fixup::pad = that slot + 1), then the final
 //    fixup over those -- a hub row of 10^6 entries is not one serial chain of
 //    thousands of dependent loads.  First-level fixups come first in the list.
+// out[row] = sum of partial[first .. first + count): one final fixup, or -- above kFixupFan slots --
+// ~sqrt(count) first-level fixups into slots of their own (allocated from nslots) and a final one.
+void add_fixups(int32_t row, int32_t first, int32_t count, int32_t &nslots, std::vector<Fixup> &level1,
+                std::vector<Fixup> &finals) {
+  constexpr int32_t kFixupFan = 32;
+  if (count <= kFixupFan) {
+    finals.push_back(Fixup{row, first, count, 0});
+    return;
+  }
+  int32_t fan = 1;
+  while (fan * fan < count) fan++;
+  const int32_t groups = (count + fan - 1) / fan;
+  finals.push_back(Fixup{row, nslots, groups, 0});
+  for (int32_t g = 0; g < groups; g++)
+    level1.push_back(Fixup{row, first + g * fan, std::min(fan, count - g * fan), ++nslots});
+}
+
 void build_sched(int32_t nrows, const int32_t *ptr, const Opts &o, Sched &s) {
   s.nrows = nrows;
   s.max_len = 0;
@@ -137,7 +154,6 @@ void build_sched(int32_t nrows, const int32_t *ptr, const Opts &o, Sched &s) {
   s.fixups.clear();
   s.nslots = 0;
   s.n_fix_l1 = 0;
-  constexpr int32_t kFixupFan = 32;
   std::vector<Fixup> finals;
   // A small schedule is latency-bound: a workgroup walks its panel's rows in 8..32 lane groups,
   // one dependent round of row loads after another, so 128-row panels turn a 2000-row graph into
@@ -172,16 +188,7 @@ void build_sched(int32_t nrows, const int32_t *ptr, const Opts &o, Sched &s) {
           const int32_t e = std::min(b + o.split_len, ptr[r + 1]);
           s.tasks.push_back(Task{r, b, e, s.nslots++});
         }
-        if (chunks <= kFixupFan) {
-          finals.push_back(Fixup{r, first, chunks, 0});
-        } else {
-          int32_t fan = 1;
-          while (fan * fan < chunks) fan++;
-          const int32_t groups = (chunks + fan - 1) / fan;
-          finals.push_back(Fixup{r, s.nslots, groups, 0});
-          for (int32_t g = 0; g < groups; g++)
-            s.fixups.push_back(Fixup{r, first + g * fan, std::min(fan, chunks - g * fan), ++s.nslots});
-        }
+        add_fixups(r, first, chunks, s.nslots, s.fixups, finals);
       }
     } else if (r - start == panel_rows ||
                ptr[r + 1] - ptr[start] > o.panel_nnz) {

@@ -28,15 +28,17 @@ def _stream_handle(device):
 
 
 def make_opts(short_max=0, split_len=0, panel_rows=0, panel_nnz=0, xcd_remap=True, host_only=False,
-              t_big=0, fused_tile_bytes=0, dfs_order=False):
+              t_big=0, fused_tile_bytes=0, dfs_order=False, hub_pass=True, fused_steps=0):
     flags = 0
     if dfs_order:
         flags |= _lib.HG_PLAN_DFS_ORDER
+    if not hub_pass:
+        flags |= _lib.HG_PLAN_NO_HUB_PASS
     if host_only:
         flags |= _lib.HG_PLAN_HOST_ONLY
     if not xcd_remap:
         flags |= _lib.HG_PLAN_NO_XCD_REMAP
-    return _lib.PlanOpts(short_max, split_len, panel_rows, panel_nnz, flags, t_big, fused_tile_bytes)
+    return _lib.PlanOpts(short_max, split_len, panel_rows, panel_nnz, flags, t_big, fused_tile_bytes, fused_steps)
 
 
 class Plan:

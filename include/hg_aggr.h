@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HG_AGGR_VERSION 100 /* major*10000 + minor*100 + patch */
+#define HG_AGGR_VERSION 200 /* major*10000 + minor*100 + patch */
 
 #if defined(__GNUC__)
 #define HG_API __attribute__((visibility("default")))
@@ -61,9 +61,13 @@ typedef enum hg_variant {
   HG_VARIANT_PUSH_ATOMIC = 2,
   /* Fused pull: vertex panels whose incident hyperedge sums are recomputed in
    * the workgroup and staged in LDS, so the M x F hyperedge feature matrix
-   * never round-trips through HBM.  Hyperedges longer than t_big and the
-   * hyperedges of hub vertices are materialised by a pre-pass instead.
-   * Same arithmetic order as HG_VARIANT_PULL. */
+   * never round-trips through HBM.  Hyperedges longer than t_big are materialised
+   * by a pre-pass instead.  Vertices with more hyperedges than a panel holds are
+   * cut into pieces (partial rows, summed by a fixup pass in a fixed order) or, the
+   * heaviest ones of a large graph, served by the hub pass: persistent workgroups
+   * that keep the hubs' running sums in registers while they stream the hyperedges,
+   * each hyperedge sum computed once per pass however many hubs it feeds.
+   * Rows of at most vdeg_max hyperedges keep HG_VARIANT_PULL's arithmetic order. */
   HG_VARIANT_FUSED = 3
 } hg_variant;
 
@@ -75,11 +79,14 @@ typedef struct hg_plan_opts {
   int32_t flags;      /* HG_PLAN_* bits                                              */
   int32_t t_big;      /* fused: recompute hyperedges of at most this many members (8)  */
   int32_t fused_tile_bytes; /* fused: LDS tile budget per workgroup -> slots per panel (16384) */
+  int32_t fused_steps; /* fused: a panel's hop-1 stream holds at most this many entries per lane group
+                          (0 = 4 entries per slot on average); 8 = one batch of row loads in flight */
 } hg_plan_opts;
 
 #define HG_PLAN_HOST_ONLY 1 /* build the schedule on the host, upload nothing (tests) */
 #define HG_PLAN_NO_XCD_REMAP 2 /* keep blockIdx -> panel identity mapping */
 #define HG_PLAN_DFS_ORDER 4 /* fused: panel rows in plain depth-first order (no greedy growth) */
+#define HG_PLAN_NO_HUB_PASS 8 /* fused: no register-hub pass; every vertex too big for a panel is cut into pieces */
 
 typedef struct hg_plan_info {
   int32_t N, M;
@@ -100,9 +107,15 @@ typedef struct hg_fused_info {
   int32_t t_big, vdeg_max;
   int32_t panels;
   int32_t n_mat;    /* materialised hyperedges */
-  int32_t n_hub;    /* hub vertices (handled by plain row gathers) */
+  int32_t n_hub;    /* register hubs: running sums kept on chip by the hub pass */
   int64_t slots;    /* sum over panels of distinct hyperedges touched */
   int64_t member_entries; /* row gathers of one fused aggregation (panels only) */
+  int32_t n_split;  /* vertices cut into pieces (panel rows that leave partial sums) */
+  int32_t fixups;   /* rows summed from partial rows after the panels (hubs + split vertices) */
+  int32_t hub_rounds, hub_workgroups; /* hub pass: rounds of hyperedge slots, persistent workgroups */
+  int64_t hub_entries; /* row gathers of the hub pass */
+  int64_t hub_pairs;   /* (hub, hyperedge) incidences served from the LDS tile */
+  int64_t partial_rows; /* partial rows in the workspace (hub parts x workgroups + pieces) */
 } hg_fused_info;
 
 HG_API int hg_version(void);

@@ -2,6 +2,8 @@
 // compiles and runs this).  Random hypergraphs of many shapes -- empty rows, hubs, duplicates,
 // one hyperedge holding everything -- through transpose_csr, build_sched and build_fused (both
 // row orders, several capacities); checks the structural invariants the kernels rely on.
+#include <climits>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
@@ -16,6 +18,181 @@
       std::exit(1);                                                  \
     }                                                                \
   } while (0)
+
+// Interpret the fused schedule exactly as the kernels do -- materialisation table, hub-pass rounds
+// (entry streams, tiles, 16-bit pair lists, register rows, partial rows per workgroup), panel records
+// (piece rows with bit 31), fixups (first level, then final) -- on exact integer "features", and
+// compare with Y = H H^T X computed directly.  Every vertex row must be written exactly once.
+static long g_hub_graphs = 0, g_hub_rounds = 0, g_hub_parts = 0, g_split_rows = 0, g_l1_fixups = 0, g_heavy = 0;
+
+static void emulate_fused(const hg::FusedSched &f, int N, int M, const std::vector<int32_t> &ptr,
+                          const std::vector<int32_t> &ind, const std::vector<int32_t> &ptr_v,
+                          const std::vector<int32_t> &ind_v, std::mt19937 &rng) {
+  std::vector<int64_t> X((size_t)N), Xe((size_t)M, 0), want((size_t)N, 0);
+  for (auto &x : X) x = (int64_t)(rng() % 1000);
+  for (int e = 0; e < M; e++)
+    for (int p = ptr[e]; p < ptr[e + 1]; p++) Xe[e] += X[ind[p]];
+  for (int v = 0; v < N; v++)
+    for (int p = ptr_v[v]; p < ptr_v[v + 1]; p++) want[v] += Xe[ind_v[p]];
+  // (a) materialised table
+  std::vector<int64_t> mat((size_t)f.n_mat, 0);
+  for (int i = 0; i < f.n_mat; i++) {
+    CHECK(f.mat_eid[i] >= 0 && f.mat_eid[i] < M);
+    for (int p = f.mat_ptr[i]; p < f.mat_ptr[i + 1]; p++) mat[i] += X[f.mat_ind[p]];
+    CHECK(mat[i] == Xe[f.mat_eid[i]]);
+  }
+  std::vector<int64_t> partial((size_t)f.n_part, INT64_MIN);
+  std::vector<int64_t> tile;
+  // heavy: if non-null, rows are 24 bits wide and bits 24..29 of a slot's last entry name the heavy
+  // hubs the finished sum is added to (hub-pass records)
+  auto run_stream = [&](const int32_t *r, int ng, int nslots, int cap, int64_t *heavy) {
+    const int steps = r[0], steps_x = r[8];
+    const int32_t *gbase = r + r[4], *stream = r + r[5];
+    CHECK(0 <= steps_x && steps_x <= steps);
+    tile.assign((size_t)nslots, INT64_MIN);
+    CHECK(nslots <= cap);
+    for (int g = 0; g < ng; g++) {
+      int slot = gbase[g];
+      int64_t sum = 0;
+      for (int s = 0; s < steps; s++) {
+        const uint32_t w = (uint32_t)stream[(size_t)s * ng + g];
+        // two phases: rows of X, then rows of the materialised table; idle = one past the phase's table
+        if ((int32_t)w == (s < steps_x ? N : f.n_mat)) continue;  // contributes zeros, never closes a slot
+        CHECK(((w & 0x40000000u) != 0) == (s >= steps_x));
+        const uint32_t row = heavy ? (w & 0x00ffffffu) : (w & 0x3fffffffu);
+        if (w & 0x40000000u) {
+          CHECK((int)row < f.n_mat);
+          sum += mat[row];
+        } else {
+          CHECK((int)row < N);
+          sum += X[row];
+        }
+        if (w & 0x80000000u) {
+          CHECK(slot >= 0 && slot < nslots && tile[slot] == INT64_MIN);
+          if (heavy)
+            for (int h = 0; h < hg::kHubHeavy; h++)
+              if ((w >> 24) & (1u << h)) {
+                CHECK(h < f.hub.n_heavy);
+                heavy[h] += sum;
+              }
+          tile[slot++] = sum;
+          sum = 0;
+        } else if (heavy) {
+          CHECK(((w >> 24) & 0x3fu) == 0);  // flags only on a slot's last entry
+        }
+      }
+      CHECK(sum == 0);  // a stream never ends inside a slot
+    }
+    for (int k = 0; k < nslots; k++) CHECK(tile[k] != INT64_MIN);
+  };
+  // (b) hub pass
+  const hg::HubPass &hp = f.hub;
+  if (hp.K > 0) {
+    CHECK(hp.nwg >= 1 && (int)hp.wg_first.size() == hp.nwg + 1 && hp.wg_first[0] == 0 &&
+          hp.wg_first[hp.nwg] == (int)hp.rec_tab.size());
+    const int nvr = hp.ng * hp.R;
+    CHECK((int)hp.vslot0.size() == nvr && hp.nv <= nvr);
+    for (int w = 0; w < hp.nwg; w++) {
+      std::vector<int64_t> acc((size_t)nvr, 0);
+      int64_t heavy[hg::kHubHeavy] = {0};
+      CHECK(hp.wg_first[w] <= hp.wg_first[w + 1] && N < (1 << 24));
+      for (int rd = hp.wg_first[w]; rd < hp.wg_first[w + 1]; rd++) {
+        const hg::HubRec &rt = hp.rec_tab[rd];
+        CHECK(rt.off >= 0 && rt.off + rt.len <= (int64_t)hp.rec.size() && rt.len % 4 == 0 && rt.len <= hp.max_rec_words &&
+              rt.len <= 8192);  // what hub_pass_kernel prefetches per round
+        const int32_t *r = hp.rec.data() + rt.off;
+        CHECK(r[1] == rt.nslots && r[10] == rt.off_eid && r[0] <= hp.max_steps);
+        run_stream(r, hp.ng, rt.nslots, hp.cap, heavy);
+        for (int k = 0; k < rt.nslots; k++) {  // slot ids vs hyperedge ids (what scaling reads)
+          const int e = r[rt.off_eid + k];
+          CHECK(e >= -1 && e < M);
+          if (e >= 0) CHECK(tile[k] == Xe[e]);
+        }
+        const uint16_t *pend = reinterpret_cast<const uint16_t *>(r + r[6]);
+        const uint16_t *pvs = reinterpret_cast<const uint16_t *>(r + r[9]);
+        CHECK(pend[nvr - 1] == r[2] && r[2] <= hp.pair_cap);
+        for (int vr = 0; vr < nvr; vr++) {
+          const int pb = vr ? pend[vr - 1] : 0, pe = pend[vr];
+          CHECK(pb <= pe);
+          for (int p = pb; p < pe; p++) {
+            CHECK(pvs[p] < rt.nslots && hp.vslot0[vr] >= 0);
+            acc[vr] += tile[pvs[p]];
+          }
+        }
+      }
+      for (int vr = 0; vr < nvr; vr++)
+        if (hp.vslot0[vr] >= 0) {
+          const int s = hp.vslot0[vr] + w;
+          CHECK(s < f.n_part && partial[s] == INT64_MIN);
+          partial[s] = acc[vr];
+        }
+      CHECK(hp.n_heavy <= hg::kHubHeavy && hp.n_heavy <= hp.K && hp.cap >= hp.ng);
+      for (int h = 0; h < hp.n_heavy; h++) {
+        const int s = hp.hslot0[h] + w;
+        CHECK(hp.hslot0[h] >= 0 && s < f.n_part && partial[s] == INT64_MIN);
+        partial[s] = heavy[h];
+      }
+    }
+  }
+  // (c) panels
+  std::vector<int> written((size_t)N, 0);
+  std::vector<int64_t> Y((size_t)N, 0);
+  for (size_t i = 0; i < f.panels.size(); i++) {
+    const auto &pn = f.panels[i];
+    const auto &rt = f.rec_tab[i];
+    CHECK(pn.nrows >= 1 && pn.nrows <= f.rows_cap && pn.nslots <= f.cap && pn.npm <= f.mem_cap && pn.nvs <= f.vslot_cap);
+    CHECK(rt.off >= 0 && rt.off + rt.len <= (int64_t)f.rec.size() && rt.len % 4 == 0 && rt.len <= f.max_rec_words);
+    const int32_t *r = f.rec.data() + rt.off;
+    CHECK(r[1] == pn.nrows && r[2] == pn.nslots && rt.nrows == pn.nrows && rt.off_prow == r[7]);
+    run_stream(r, f.ng, pn.nslots, f.cap, nullptr);
+    const uint16_t *pend = reinterpret_cast<const uint16_t *>(r + r[6]);
+    const uint16_t *pvs = reinterpret_cast<const uint16_t *>(r + r[9]);
+    const int32_t *prow = r + r[7];
+    for (int k = 0; k < pn.nrows; k++) {
+      const int pb = k ? pend[k - 1] : 0, pe = pend[k];
+      int64_t sum = 0;
+      for (int p = pb; p < pe; p++) {
+        CHECK(pvs[p] < pn.nslots);
+        sum += tile[pvs[p]];
+      }
+      if (prow[k] < 0) {
+        const int s = prow[k] & 0x7fffffff;
+        CHECK(s < f.n_part && partial[s] == INT64_MIN);
+        partial[s] = sum;
+      } else {
+        CHECK(prow[k] < N);
+        written[prow[k]]++;
+        Y[prow[k]] = sum;
+      }
+    }
+  }
+  // (d) fixups: first level into slots of their own, then the final ones into Y
+  CHECK(f.n_fix_l1 <= (int)f.fixups.size());
+  for (size_t i = 0; i < f.fixups.size(); i++) {
+    const hg::Fixup &fx = f.fixups[i];
+    CHECK(fx.first >= 0 && fx.count >= 1 && fx.first + fx.count <= f.n_part && fx.row >= 0 && fx.row < N);
+    int64_t sum = 0;
+    for (int k = 0; k < fx.count; k++) {
+      CHECK(partial[fx.first + k] != INT64_MIN);
+      sum += partial[fx.first + k];
+    }
+    if ((int)i < f.n_fix_l1) {
+      CHECK(fx.pad >= 1 && fx.pad <= f.n_part && partial[fx.pad - 1] == INT64_MIN);
+      partial[fx.pad - 1] = sum;
+    } else {
+      CHECK(fx.pad == 0);
+      written[fx.row]++;
+      Y[fx.row] = sum;
+    }
+  }
+  for (int v = 0; v < N; v++) CHECK(written[v] == 1 && Y[v] == want[v]);
+  g_hub_graphs += hp.K > 0;
+  g_hub_rounds += (long)hp.rec_tab.size();
+  g_heavy += hp.n_heavy;
+  g_hub_parts += hp.nv - hp.K;
+  g_split_rows += f.n_split;
+  g_l1_fixups += f.n_fix_l1;
+}
 
 static void one_graph(std::mt19937 &rng, int N, int M, double mean, int hub_every, bool mega) {
   std::vector<int32_t> ptr(1, 0), ind;
@@ -74,30 +251,24 @@ static void one_graph(std::mt19937 &rng, int N, int M, double mean, int hub_ever
       for (const auto &fx : s.fixups) CHECK(fx.first >= 0 && fx.count >= 1 && fx.first + fx.count <= s.nslots && fx.pad <= s.nslots);
     }
     for (int cap : {16, 64, 128}) {
-      hg::FusedSched f;
-      hg::build_fused(N, M, ptr.data(), ind.data(), ptr_v.data(), ind_v.data(), o, cap, cap * 4, 32, f);
-      std::vector<int> seen_v((size_t)N, 0);
-      for (int32_t v : f.prow) seen_v[v]++;
-      for (int32_t v : f.hub_vid) seen_v[v]++;
-      for (int v = 0; v < N; v++) CHECK(seen_v[v] == 1);  // every vertex exactly once
-      int64_t n_mat = 0, n_hub = 0;
-      hg::classify_fused(N, M, ptr.data(), ptr_v.data(), ind_v.data(), o, cap, cap * 4, &n_mat, &n_hub);
-      CHECK(n_mat == f.n_mat && n_hub == f.n_hub);
-      CHECK(f.rec_tab.size() == f.panels.size());
-      for (size_t i = 0; i < f.panels.size(); i++) {
-        const auto &pn = f.panels[i];
-        const auto &rt = f.rec_tab[i];
-        CHECK(pn.nrows >= 1 && pn.nrows <= f.rows_cap && pn.nslots <= f.cap && pn.npm <= f.mem_cap);
-        CHECK(rt.off >= 0 && rt.off + rt.len <= (int64_t)f.rec.size() && rt.len % 4 == 0 && rt.len <= f.max_rec_words);
-        const int32_t *r = f.rec.data() + rt.off;
-        CHECK(r[1] == pn.nrows && r[2] == pn.nslots);
-        const int steps = r[0];
-        for (int k = 0; k < steps * f.ng; k++) {
-          const uint32_t w = (uint32_t)r[r[5] + k];
-          if ((int32_t)w == N) continue;  // idle
-          const uint32_t row = w & 0x3fffffffu;
-          CHECK((w & 0x40000000u) ? (int)row < f.n_mat : (int)row < N);
+      for (int hubs = 0; hubs < 2; hubs++) {
+        hg::Opts oh = o;
+        if (hubs) {  // reach the hub pass on these small graphs
+          oh.hub_min_nnz = 0;
+          oh.hub_min_deg = 2;
+          if (cap != 64) oh.hub_tile_bytes = 16384;  // 32-slot rounds: many rounds, many workgroups
+        } else {
+          oh.flags |= HG_PLAN_NO_HUB_PASS;
         }
+        hg::FusedSched f;
+        // 8 lanes x 4 floats per row, as F = 32; or (small hub tiles) 32 lanes x 4 floats, as F = 128
+        const int ng = (hubs && cap != 64) ? 8 : 32, row_floats = (hubs && cap != 64) ? 128 : 32;
+        hg::build_fused(N, M, ptr.data(), ind.data(), ptr_v.data(), ind_v.data(), oh, cap, cap * 4, ng, row_floats, true, f);
+        int64_t n_mat = 0, n_big = 0;
+        hg::classify_fused(N, M, ptr.data(), ptr_v.data(), ind_v.data(), oh, cap, cap * 4, &n_mat, &n_big);
+        CHECK(n_mat == f.n_mat && n_big == f.n_split + f.hub.K);
+        CHECK(f.rec_tab.size() == f.panels.size());
+        emulate_fused(f, N, M, ptr, ind, ptr_v, ind_v, rng);
       }
     }
   }
@@ -156,6 +327,10 @@ int main(int argc, char **argv) {
     const int N = 1 + (int)(rng() % (it % 20 == 0 ? 4000 : 400)), M = (int)(rng() % (it % 20 == 0 ? 3000 : 300));
     one_graph(rng, N, M, 0.5 + (it % 7) * 2.0, it % 3 == 0 ? 2 : 0, it % 11 == 5);
   }
+  // the random graphs must actually have reached the hub pass, hub parts, split rows and two-level fixups
+  std::printf("hub schedules %ld, hub rounds %ld, heavy hubs %ld, extra hub parts %ld, split vertices %ld, first-level fixups %ld\n",
+              g_hub_graphs, g_hub_rounds, g_heavy, g_hub_parts, g_split_rows, g_l1_fixups);
+  CHECK(g_heavy > 50 && g_hub_graphs > 50 && g_hub_rounds > 10 * g_hub_graphs && g_hub_parts > 0 && g_split_rows > 100 && g_l1_fixups > 0);
   std::puts("sched_fuzz ok");
   return 0;
 }
