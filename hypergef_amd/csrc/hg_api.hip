@@ -292,7 +292,11 @@ int pick_variant_uncached(const hg_plan *plan, int32_t F, bool vec4, int32_t *va
   const hg::FusedSched &fs = **f;
   const int64_t mat_nnz = fs.mat_ptr.empty() ? 0 : fs.mat_ptr.back();
   const bool work_ok = small || fs.pmem_entries + fs.hub.stream_entries + mat_nnz <= 5 * plan->nnz;
-  if (work_ok) *variant = HG_VARIANT_FUSED;
+  // vertices cut into pieces pay for partial rows and a fixup pass: where they are more than 1/16 of the
+  // vertices (yelp-shape: average degree 58, every second vertex above a panel's 64 hyperedges) the
+  // pull path wins by 15-40 % (profiles/r02_variant_choice.md)
+  const bool pieces_ok = small || (int64_t)fs.n_split * 16 <= plan->N;
+  if (work_ok && pieces_ok) *variant = HG_VARIANT_FUSED;
   return HG_OK;
 }
 

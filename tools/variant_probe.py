@@ -22,9 +22,9 @@ for name in (sys.argv[1:] or list(synth.ALLSET_SHAPES)):
         X = torch.rand(inc.N, F, device=dev); Y = torch.empty_like(X)
         for tb in (0,):
             pl = planmod.Plan.from_tensors(inc.N, ptr, ind, planmod.make_opts(t_big=tb))
+            info = pl.prepare(F)  # before sizing the workspace: the fused schedule's partial rows count
             ws = torch.empty(max(pl.workspace_bytes(F),256), dtype=torch.uint8, device=dev)
-            info = pl.prepare(F)
             res = {}
             for v in ('auto','pull','fused'):
                 res[v] = t_us(lambda: pl.aggregate(ptr, ind, X, out=Y, workspace=ws, variant=v))
-            print(' F',F,'t_big',tb, pl.auto_variant(F), {k: round(x,2) for k,x in res.items()}, {k:info[k] for k in ('cap','panels','n_mat','n_hub','slots','member_entries')})
+            print(' F',F,'t_big',tb, pl.auto_variant(F), {k: round(x,2) for k,x in res.items()}, {k:info[k] for k in ('cap','panels','n_mat','n_hub','n_split','member_entries')})
