@@ -236,7 +236,7 @@ def run_config(shape, replicas, F, weighted, variant, steps, warmup, dev, sync, 
         hyperg = hg.HyperGraph.from_incidence(inc, dev, ngs=1 << 30)
         degE, degV = hyperg.degE.reshape(-1), hyperg.degV.reshape(-1)
         degE = torch.where(torch.isinf(degE), torch.zeros_like(degE), degE)
-        W = torch.rand(inc.M, device=dev) + 0.5
+        W = torch.ones(inc.M, device=dev)  # HGNNConv's Wdiag (model/ugsys/hgnn.py:12); random W: tests/test_gpu_parity.py
         scales_host = (degE.cpu().numpy(), degV.cpu().numpy(), W.cpu().numpy())
         n_w = 2
     Y = torch.empty((inc.N, F), dtype=torch.float32, device=dev)

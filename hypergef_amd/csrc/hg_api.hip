@@ -534,6 +534,7 @@ int hg_plan_bind_scales(const hg_plan *cp, int32_t F, const float *degE, const f
   std::lock_guard<std::mutex> lock(const_cast<hg_plan *>(cp)->fused_mu);
   if (!degE && !degV && !W) {  // unbind: later calls gather their scales themselves
     f->bound_degE = f->bound_W = f->bound_degV = nullptr;
+    f->bound_W_is_one = false;
     return HG_OK;
   }
   const size_t ns = f->eid_all.size(), nr = f->prow.size();
@@ -545,9 +546,25 @@ int hg_plan_bind_scales(const hg_plan *cp, int32_t F, const float *degE, const f
   hipError_t e = hg::launch_bind_scales((int64_t)ns, f->d_eid_all, degE, W, f->d_bsA, f->d_bsB, (int64_t)nr,
                                         f->d_prow, degV, f->d_bsD, static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return hip_fail("bind_scales launch", e);
+  // W = ones is what the reference's models pass (model/ugsys/hgnn.py:12): x * 1.0f is x, so a bound all-ones W
+  // is left out of the kernels.  One 4-byte read-back: this call synchronises `stream` when W is given.
+  bool w_one = false;
+  if (W && cp->M > 0) {
+    int32_t *d_flag = nullptr, h_flag = 1;
+    HG_HIP(hipMalloc(reinterpret_cast<void **>(&d_flag), sizeof(int32_t)));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipError_t e2 = hipMemcpyAsync(d_flag, &h_flag, sizeof(int32_t), hipMemcpyHostToDevice, st);
+    if (e2 == hipSuccess) e2 = hg::launch_all_ones(cp->M, W, d_flag, st);
+    if (e2 == hipSuccess) e2 = hipMemcpyAsync(&h_flag, d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+    if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);
+    (void)hipFree(d_flag);
+    if (e2 != hipSuccess) return hip_fail("bind_scales: all-ones check", e2);
+    w_one = h_flag != 0;
+  }
   f->bound_degE = degE;
   f->bound_W = W;
   f->bound_degV = degV;
+  f->bound_W_is_one = w_one;
   return HG_OK;
 }
 
@@ -739,6 +756,9 @@ static int aggr_impl(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
       return HG_ERR_WORKSPACE;
     }
     float *partial = reinterpret_cast<float *>(ws + fc.part);
+    // scales pre-gathered into panel order, if the caller bound exactly these arrays
+    const bool bound = (degE || degV || W) && f->bound_degE == degE && f->bound_W == W && f->bound_degV == degV;
+    if (bound && W && f->bound_W_is_one) W = nullptr;  // multiplying by exactly 1.0f is the identity: same bits, less work
     const int64_t xb = (int64_t)plan->N * F * 4, mb = (int64_t)f->n_mat * F * 4;
     const int32_t x_bytes = xb < ((int64_t)1 << 31) ? (int32_t)xb : 0;
     const int32_t mat_bytes = mb < ((int64_t)1 << 31) ? (int32_t)mb : 0;
@@ -797,8 +817,6 @@ static int aggr_impl(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
     a.mat_bytes = mat_bytes;
     a.nrows_x = plan->N;
     a.nrows_mat = f->n_mat;
-    // scales pre-gathered into panel order, if the caller bound exactly these arrays
-    const bool bound = (degE || degV || W) && f->bound_degE == degE && f->bound_W == W && f->bound_degV == degV;
     a.bsA = bound ? f->d_bsA : nullptr;
     a.bsB = bound ? f->d_bsB : nullptr;
     a.bsD = bound ? f->d_bsD : nullptr;

@@ -149,6 +149,7 @@ struct FusedSched {
   int32_t *d_eid_all = nullptr;
   float *d_bsA = nullptr, *d_bsB = nullptr, *d_bsD = nullptr;
   const float *bound_degE = nullptr, *bound_W = nullptr, *bound_degV = nullptr;
+  bool bound_W_is_one = false;  // every W[e] was exactly 1.0f when bound: multiplying by it is the identity
 };
 
 struct Opts {

@@ -119,6 +119,8 @@ hipError_t launch_push(const PushArgs &a, hipStream_t stream);
 hipError_t launch_bind_scales(int64_t nslots, const int32_t *eid_all, const float *degE, const float *W,
                               float *bsA, float *bsB, int64_t nrows, const int32_t *prow, const float *degV,
                               float *bsD, hipStream_t stream);
+// *flag (device int32, preset to 1) is cleared if any of W[0..n) differs from 1.0f
+hipError_t launch_all_ones(int64_t n, const float *W, int32_t *flag, hipStream_t stream);
 hipError_t launch_gather_max(int32_t M, int32_t F, const int32_t *ptr, const int32_t *ind, const float *X,
                              const float *degE, const float *W, float *Xe, int32_t *record,
                              hipStream_t stream);

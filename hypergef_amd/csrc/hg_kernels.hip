@@ -668,8 +668,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LIN ? (LPR 
   if (a.degE || a.W)
     for (int i = tid; i < rt.nslots; i += BS) {
       if (a.bsA) {  // bound: one coalesced read instead of a scattered 4-byte gather per slot
-        sA[i] = a.bsA[rt.slot_base + i];
-        sB[i] = a.bsB[rt.slot_base + i];
+        if (a.degE) sA[i] = a.bsA[rt.slot_base + i];
+        if (a.W) sB[i] = a.bsB[rt.slot_base + i];
       } else {
         const int e = a.eid_all[rt.slot_base + i];  // -1: materialised row, already scaled
         sA[i] = (a.degE && e >= 0) ? a.degE[e] : 1.f;
@@ -1552,6 +1552,22 @@ hipError_t launch_bind_scales(int64_t nslots, const int32_t *eid_all, const floa
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(bind_scales_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, nslots,
                      eid_all, degE, W, bsA, bsB, nrows, prow, degV, bsD);
+  return hipGetLastError();
+}
+
+// The reference's models pass W = ones (model/ugsys/hgnn.py:12).  Multiplying by exactly 1.0f changes no bit,
+// so a bound all-ones W is dropped from the kernels' argument lists (hg_plan_bind_scales).
+__global__ __launch_bounds__(256) void all_ones_kernel(int64_t n, const float *W, int32_t *flag) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  bool ok = true;
+  for (; i < n; i += (int64_t)gridDim.x * 256) ok = ok && W[i] == 1.0f;
+  if (__builtin_amdgcn_ballot_w64(!ok) != 0 && (threadIdx.x & 63) == 0) *flag = 0;
+}
+
+hipError_t launch_all_ones(int64_t n, const float *W, int32_t *flag, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  const unsigned blocks = (unsigned)std::min<int64_t>(1024, (n + 255) / 256);
+  hipLaunchKernelGGL(all_ones_kernel, dim3(blocks), dim3(256), 0, stream, n, W, flag);
   return hipGetLastError();
 }
 

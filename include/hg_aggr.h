@@ -183,6 +183,9 @@ HG_API int hg_plan_prepare(const hg_plan *plan, int32_t F, hg_fused_info *info);
  * contents; passing other pointers simply bypasses the binding, and binding three NULL
  * pointers removes it (later calls gather their scales themselves: the safe choice for
  * vectors another library rewrites in place).  The binding is keyed on addresses only.
+ * When W is given the call also checks once whether every W[e] is exactly 1.0f (what the
+ * reference's models pass, model/ugsys/hgnn.py:12) and, if so, later calls skip that
+ * multiplication -- the identity, bit for bit; this check synchronises `stream`.
  * Allocates on the first call per width (not capturable); enqueues one small kernel on
  * `stream` -- a caller that aggregates on a different stream orders the two itself. */
 HG_API int hg_plan_bind_scales(const hg_plan *plan, int32_t F, const float *degE,
