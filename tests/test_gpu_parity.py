@@ -1007,3 +1007,49 @@ def test_lds_budget_is_checked_up_front(hg):
     assert torch.equal(big.aggregate(ptr, ind, X, variant="pull"), y0)      # 131 KB of LDS per workgroup
     yf = big.aggregate(ptr, ind, X, variant="fused")                          # 128 KB tile + record
     assert torch.allclose(yf, y0, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("F", [16, 20, 32, 64, 128, 320, 33])
+def test_hub_pass_feature_widths(hg, oracle, F):
+    """The hub pass (register hubs, heavy-hub flags, pieces, both fixup levels) at every lane layout:
+    a power-law hypergraph just above the size where the pass engages (1.4 M incidences, a vertex in
+    ~10^5 hyperedges), forced `variant="fused"`.  F = 16 .. 128: 4 .. 32 lanes per row; F = 320: two
+    column tiles; F = 20: a padded tile row; F = 33: dword lanes -- no hub pass, pieces take every big
+    vertex.  Checked against the float64 answer at 1e-5 (the fp32 oracle's own chains are the less
+    accurate side on hub rows, see test_config4_powerlaw_full_size), unweighted and weighted."""
+    from hypergef_amd.plan import Plan, make_opts
+    inc = synth.powerlaw(80_000, 300_000, seed=5)
+    rng = np.random.default_rng(F)
+    X = rng.standard_normal((inc.N, F)).astype(np.float32)
+    degE, degV = oracle.degrees(inc.N, inc.M, inc.csrptr, inc.colind)
+    degE = np.where(np.isinf(degE), 0, degE).astype(np.float32)
+    W = (rng.random(inc.M) + 0.5).astype(np.float32)
+    ptr, ind, Xd = _dev(inc.csrptr), _dev(inc.colind), _dev(X)
+    plan = Plan.from_tensors(inc.N, ptr, ind)
+    info = plan.prepare(F)
+    assert (info["n_hub"] > 100 and info["hub_rounds"] > 100) == (F % 4 == 0), info
+    assert info["n_split"] > 0 and info["fixups"] >= info["n_hub"] + info["n_split"]
+    no_hub = Plan.from_tensors(inc.N, ptr, ind, make_opts(hub_pass=False))
+    assert no_hub.prepare(F)["n_hub"] == 0
+
+    truth = _float64_truth(inc, X)
+    # sums of n standard-normal terms: the answer's own magnitude is ~sqrt(n); bound relative to the row's
+    # l1 mass, as a sum's rounding error is (|x| terms, not the cancelled result)
+    mass = _float64_truth(inc, np.abs(X))
+    y = plan.aggregate(ptr, ind, Xd, variant="fused").cpu().numpy()
+    assert (np.abs(y - truth) <= 1e-5 * np.maximum(1.0, mass)).all()
+    y2 = no_hub.aggregate(ptr, ind, Xd, variant="fused").cpu().numpy()
+    assert (np.abs(y2 - truth) <= 1e-5 * np.maximum(1.0, mass)).all()
+    yp = plan.aggregate(ptr, ind, Xd, variant="pull").cpu().numpy()
+    assert (np.abs(y - yp) <= 2e-5 * np.maximum(1.0, mass)).all()
+    # deterministic: same bits on a second call
+    assert np.array_equal(y, plan.aggregate(ptr, ind, Xd, variant="fused").cpu().numpy())
+    if F in (32, 128):
+        truth_w = _float64_truth(inc, X, degE, degV, W)
+        mass_w = _float64_truth(inc, np.abs(X), degE, degV, W)
+        yw = plan.aggregate(ptr, ind, Xd, _dev(degE.ravel()), _dev(degV.ravel()), _dev(W), variant="fused").cpu().numpy()
+        assert (np.abs(yw - truth_w) <= 1e-5 * np.maximum(1e-3, mass_w)).all()
+        # unbound scales (the kernels gather degE / W / degV themselves) give the same bits
+        yu = plan.aggregate(ptr, ind, Xd, _dev(degE.ravel()), _dev(degV.ravel()), _dev(W), variant="fused",
+                            bind_scales=False).cpu().numpy()
+        assert np.array_equal(yw, yu)
