@@ -198,8 +198,14 @@ HG_API int hg_plan_auto_variant(const hg_plan *plan, int32_t F);
  * first_slot, count, 0}; sizes from hg_plan_get_info.  Pointers may be NULL. */
 HG_API int hg_plan_get_schedule(const hg_plan *plan, int32_t hop, int32_t *panels,
                                 int32_t *tasks, int32_t *fixups);
-/* Bytes of scratch hg_aggr_fused_f32 needs for feature width F (the M x F
- * hyperedge feature matrix plus partial-sum slots), a multiple of 256. */
+/* Bytes of scratch hg_aggr_fused_f32 needs for feature width F, a multiple of 256: the larger
+ * of the pull layout (the M x F hyperedge feature matrix plus partial-sum slots) and, once the
+ * width's fused schedule exists, its layout (materialised rows, partial rows of hub vertices and
+ * pieces).  The call resolves HG_VARIANT_AUTO for this width first -- building the fused schedule
+ * on the host if that is the choice (once per width; milliseconds for dataset-sized graphs,
+ * seconds for 10^7 incidences) -- so the size covers what an AUTO call will run.  A caller that
+ * forces HG_VARIANT_FUSED on a plan whose AUTO choice is pull calls hg_plan_prepare first; a
+ * fused call with a workspace sized before that returns HG_ERR_WORKSPACE, never writes past it. */
 HG_API size_t hg_plan_workspace_bytes(const hg_plan *plan, int32_t F);
 
 /* ---- the hot path ------------------------------------------------------------

@@ -302,6 +302,7 @@ int main(int argc, char **argv) {
   {  // this backend's kernels
     hg_plan *plan = nullptr;
     HG_OKAY(hg_plan_create_host(&plan, N, M, Tp, Ti, nullptr));
+    HG_OKAY(hg_plan_prepare(plan, F, nullptr));  // both variants are timed: the fused schedule's partial rows count
     const size_t wsb = hg_plan_workspace_bytes(plan, F);
     void *ws = nullptr;
     HIP_OK(hipMalloc(&ws, std::max<size_t>(wsb, 256)));
