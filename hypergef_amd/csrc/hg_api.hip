@@ -39,7 +39,10 @@ int resolve_opts(const hg_plan_opts *in, hg::Opts &o) {
     if (in->panel_nnz > 0) o.panel_nnz = in->panel_nnz;
     o.flags = in->flags;
     if (in->t_big > 0) o.t_big = in->t_big;
-    if (in->fused_tile_bytes > 0) o.fused_tile_bytes = in->fused_tile_bytes;
+    if (in->fused_tile_bytes > 0) {
+      o.fused_tile_bytes = in->fused_tile_bytes;
+      o.fused_tile_auto = false;
+    }
     if (in->fused_steps > 0) o.fused_steps = in->fused_steps;
   }
   if (o.short_max > o.panel_nnz || o.split_len < o.short_max || o.panel_rows > 4096 ||
@@ -125,15 +128,27 @@ void fused_free(hg::FusedSched &f) {
 
 // Capacities of a fused panel for feature width F: `cap` hyperedge slots (rows of the
 // LDS tile, whole multiples of 16), four stream entries per slot on average.
-void fused_caps(const hg_plan *p, int32_t F, bool vec4, int32_t &cap, int32_t &mem_cap) {
+void fused_caps(const hg_plan *p, int32_t F, bool vec4, int32_t &cap, int32_t &mem_cap, int32_t tile_bytes = 0) {
   const int row_bytes = hg::fused_tile_row_floats(F, vec4) * 4;
-  const int c = std::max(16, std::min(256, p->opts.fused_tile_bytes / row_bytes));
+  const int c = std::max(16, std::min(256, (tile_bytes > 0 ? tile_bytes : p->opts.fused_tile_bytes) / row_bytes));
   cap = c / 16 * 16;
   mem_cap = cap * 4;
   if (p->opts.fused_steps > 0) {  // whole batches of the kernel's row loads: steps x lane groups
     const int32_t ng = 256 / (hg::fused_tile_row_floats(F, vec4) / (vec4 ? 4 : 1));
     mem_cap = std::max(p->opts.t_big, std::min(mem_cap, p->opts.fused_steps * ng));
   }
+}
+
+// A small hypergraph (nnz <= 2^18) is launch-bound: what one aggregation costs is the number of dependent
+// launches and the longest dependent chain inside a workgroup, not bytes.  Model fitted on single cora /
+// citeseer / pubmed-shape hypergraphs at F = 32 (profiles/r02_experiments.md, device us per aggregation):
+// 5 us per launch (panels, + materialisation pre-pass, + fixup pass), 0.08 us per step of the longest hop-1
+// stream, 0.4 us per row a lane group sums in hop 2.
+double small_graph_cost(const hg::FusedSched &f) {
+  int32_t max_rows = 0;
+  for (const hg::FPanel &pn : f.panels) max_rows = std::max(max_rows, pn.nrows);
+  const int launches = 1 + (f.n_mat > 0 ? 1 : 0) + (f.fixups.empty() ? 0 : 1);
+  return 5.0 * launches + 0.08 * f.max_steps + 0.4 * ((max_rows + f.ng - 1) / std::max(1, f.ng));
 }
 
 // The F-dependent part of the plan, built on first use (guarded by the plan's mutex).
@@ -155,19 +170,41 @@ int get_fused(const hg_plan *cp, int32_t F, bool vec4, const hg::FusedSched **ou
     try {
       hg::build_fused(p->N, p->M, p->ptr_t.data(), p->ind_t.data(), p->ptr_v.data(), p->ind_v.data(),
                       p->opts, cap, mem_cap, ng, row_floats, allow_hub, f);
-      // A small hypergraph is launch-bound.  If the default schedule needs a materialisation
-      // launch only because of a few longish hyperedges, try recomputing them too and keep
-      // that schedule when the launch saved (~5 us) outweighs its longer streams (~0.08 us
-      // per step of the longest panel): one citeseer-shape hypergraph 15.8 -> 8.2 us,
-      // coauthor_cora-shape 12.6 -> 9.6 us at F = 32; pubmed-shape keeps materialising.
-      if (p->nnz <= (1 << 18) && f.n_mat > 0 && f.n_split == 0 && p->sched[0].max_len * 4 <= mem_cap) {
-        hg::Opts o = p->opts;
-        o.t_big = std::max(o.t_big, p->sched[0].max_len);
-        hg::FusedSched alt;
-        hg::build_fused(p->N, p->M, p->ptr_t.data(), p->ind_t.data(), p->ptr_v.data(), p->ind_v.data(), o, cap,
-                        mem_cap, ng, row_floats, allow_hub, alt);
-        const double cost_default = 10.0 + 0.08 * f.max_steps, cost_alt = 5.0 + 0.08 * alt.max_steps;
-        if (alt.n_mat == 0 && alt.n_split == 0 && cost_alt < cost_default) f = std::move(alt);
+      // A small hypergraph is launch-bound (small_graph_cost).  Two things can shorten it: recomputing the
+      // few longish hyperedges too instead of a materialisation launch (one citeseer-shape hypergraph
+      // 15.8 -> 8.2 us at F = 32), and -- unless the caller fixed the tile -- smaller panels: more, shorter
+      // workgroups on a chip that 25 panels leave nine tenths empty (one cora-shape hypergraph at F = 32:
+      // 128 / 64 / 32-slot panels 5.4 / 4.3 / 3.8 us).  All candidates are built, the cheapest is kept.
+      if (p->nnz <= (1 << 18)) {
+        double best = small_graph_cost(f);
+        const int32_t tiles[3] = {p->opts.fused_tile_bytes, p->opts.fused_tile_bytes / 2, p->opts.fused_tile_bytes / 4};
+        for (int t = 0; t < (p->opts.fused_tile_auto ? 3 : 1); t++) {
+          int32_t c2, m2;
+          fused_caps(p, F, vec4, c2, m2, tiles[t]);
+          if (t > 0 && c2 == cap) continue;
+          // mode 0: the default rule (materialise above t_big); 1: recompute every hyperedge whole;
+          // 2, 3: cut hyperedges above 8 / 16 members into sub-slots (Opts::slot_chunk)
+          for (int mode = 0; mode < 4; mode++) {
+            if (t == 0 && mode == 0) continue;  // that is f
+            hg::Opts o = p->opts;
+            if (mode == 1) {
+              if (p->sched[0].max_len * 4 > m2 || p->sched[0].max_len <= o.t_big) continue;
+              o.t_big = p->sched[0].max_len;
+            } else if (mode >= 2) {
+              o.slot_chunk = std::max(o.t_big, mode == 2 ? 8 : 16);
+              if (p->sched[0].max_len <= o.slot_chunk || (mode == 3 && o.t_big >= 16)) continue;
+            }
+            hg::FusedSched alt;
+            hg::build_fused(p->N, p->M, p->ptr_t.data(), p->ind_t.data(), p->ptr_v.data(), p->ind_v.data(), o, c2, m2,
+                            ng, row_floats, allow_hub, alt);
+            if (alt.invalid) continue;
+            const double c = small_graph_cost(alt);
+            if (c < best) {
+              best = c;
+              f = std::move(alt);
+            }
+          }
+        }
       }
     } catch (const std::bad_alloc &) {
       hg::set_error("fused schedule: host allocation failed");
@@ -291,6 +328,10 @@ int pick_variant_uncached(const hg_plan *plan, int32_t F, bool vec4, int32_t *va
   // entries -- one launch, no Xe round trip, re-gathered rows mostly L2 hits.
   const hg::FusedSched &fs = **f;
   const int64_t mat_nnz = fs.mat_ptr.empty() ? 0 : fs.mat_ptr.back();
+  // small graphs: two dependent launches either way once the fused schedule needs a materialisation or fixup
+  // pass, and then the pull kernels are the lighter pair (single pubmed / coauthor_cora / Mushroom / 20news /
+  // house-committees shapes: pull 5-25 % ahead; profiles/r02_variant_choice.md)
+  if (small && (fs.n_mat > 0 || !fs.fixups.empty())) return HG_OK;
   const bool work_ok = small || fs.pmem_entries + fs.hub.stream_entries + mat_nnz <= 5 * plan->nnz;
   // vertices cut into pieces pay for partial rows and a fixup pass: where they are more than 1/16 of the
   // vertices (yelp-shape: average degree 58, every second vertex above a panel's 64 hyperedges) the

@@ -140,12 +140,15 @@ void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_
   f.vdeg_max = std::max(1, std::min(std::min(cap, f.vslot_cap), f.mem_cap / f.t_big));
   const int64_t nnz = ptr_t[M];
 
+  // sub-slots per hyperedge (Opts::slot_chunk; 1 everywhere in the default schedule)
+  const int32_t chunk = o.slot_chunk > 0 ? std::max(o.slot_chunk, f.t_big) : 0;
+  auto nsub = [&](int32_t e) { return chunk > 0 ? std::max(1, (ptr_t[e + 1] - ptr_t[e] + chunk - 1) / chunk) : 1; };
   // materialised hyperedges: compact CSR over their members
   std::vector<uint8_t> is_mat((size_t)M, 0);
   std::vector<int32_t> mat_id((size_t)M, -1);
   f.mat_ptr.push_back(0);
   for (int32_t e = 0; e < M; e++)
-    if (ptr_t[e + 1] - ptr_t[e] > f.t_big) {
+    if (chunk == 0 && ptr_t[e + 1] - ptr_t[e] > f.t_big) {
       is_mat[e] = 1;
       mat_id[e] = f.n_mat++;
       f.mat_eid.push_back(e);
@@ -158,11 +161,21 @@ void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_
   // big[v]: 1 = register hub, 2 = split into pieces
   std::vector<uint8_t> big((size_t)N, 0);
   std::vector<int32_t> cand;
-  for (int32_t v = 0; v < N; v++)
-    if (ptr_v[v + 1] - ptr_v[v] > f.vdeg_max) {
+  for (int32_t v = 0; v < N; v++) {
+    int64_t w = ptr_v[v + 1] - ptr_v[v];
+    if (chunk > 0) {
+      w = 0;
+      for (int32_t p = ptr_v[v]; p < ptr_v[v + 1]; p++) w += nsub(ind_v[p]);
+      if (w > std::min(f.vdeg_max, f.mem_cap / chunk)) {  // would need pieces cut by sub-slot count: not worth it on a launch-bound graph
+        f.invalid = true;
+        return;
+      }
+    }
+    if (w > f.vdeg_max) {
       big[v] = 2;
       cand.push_back(v);
     }
+  }
   std::vector<int32_t> hub_of((size_t)N, -1), parts;
   HubPass &hp = f.hub;
   hub_geometry(ng, row_floats, o.hub_tile_bytes, hp);
@@ -310,15 +323,15 @@ void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_
   // vertex), written to `dest` (vertex id, or 0x80000000 | partial slot).
   auto add_row = [&](int32_t v, int32_t p0, int32_t p1, int32_t dest, bool feed_greedy) {
     int32_t pid = (int32_t)f.panels.size();
-    int32_t new_slots = 0, new_mem = 0;
+    int32_t new_slots = 0, new_mem = 0, deg = 0;
     for (int32_t p = p0; p < p1; p++) {
       const int32_t e = ind_v[p];
+      deg += nsub(e);
       if (stamp[e] != pid) {  // a duplicate incidence is counted twice here; harmless
-        new_slots++;
+        new_slots += nsub(e);
         new_mem += is_mat[e] ? 1 : (ptr_t[e + 1] - ptr_t[e]);
       }
     }
-    const int32_t deg = p1 - p0;
     const int32_t rows = (int32_t)f.prow.size() - cur.r0;
     const int32_t cur_mem = (int32_t)f.pmem.size() - cur.pm0;
     const int32_t cur_vs = (int32_t)f.pvs.size() - cur.v0;
@@ -332,15 +345,23 @@ void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_
     if (greedy && feed_greedy) done[v] = 1;
     for (int32_t p = p0; p < p1; p++) {
       const int32_t e = ind_v[p];
+      const int32_t k = nsub(e);
       if (stamp[e] != pid) {
         stamp[e] = pid;
-        slot_of[e] = cur.nslots++;
+        slot_of[e] = cur.nslots;
+        cur.nslots += k;
         if (is_mat[e]) {
           f.pmem.push_back((int32_t)(0x80000000u | (uint32_t)mat_id[e]));
           f.slot_eid.push_back(-1);
+          f.soff.push_back((int32_t)f.pmem.size() - cur.pm0);
         } else {
-          f.pmem.insert(f.pmem.end(), ind_t + ptr_t[e], ind_t + ptr_t[e + 1]);
-          f.slot_eid.push_back(e);
+          const int32_t len = ptr_t[e + 1] - ptr_t[e];
+          for (int32_t j = 0; j < k; j++) {  // k = 1: the whole hyperedge; else chunks of `chunk` members
+            const int32_t b0 = ptr_t[e] + (k > 1 ? j * chunk : 0), b1 = k > 1 ? std::min(b0 + chunk, ptr_t[e] + len) : ptr_t[e] + len;
+            f.pmem.insert(f.pmem.end(), ind_t + b0, ind_t + b1);
+            f.slot_eid.push_back(e);
+            f.soff.push_back((int32_t)f.pmem.size() - cur.pm0);
+          }
           if (greedy && feed_greedy)
             for (int32_t q = ptr_t[e]; q < ptr_t[e + 1]; q++) {
               const int32_t u = ind_t[q];
@@ -350,9 +371,8 @@ void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_
               std::push_heap(heap.begin(), heap.end());
             }
         }
-        f.soff.push_back((int32_t)f.pmem.size() - cur.pm0);
       }
-      f.pvs.push_back((uint16_t)slot_of[e]);
+      for (int32_t j = 0; j < k; j++) f.pvs.push_back((uint16_t)(slot_of[e] + j));
     }
     f.prow.push_back(dest);
     f.pend.push_back((int32_t)f.pvs.size() - cur.v0);

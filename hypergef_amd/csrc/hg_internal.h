@@ -116,6 +116,7 @@ struct FusedSched {
   int32_t vdeg_max = 0;   // vertices with more incident hyperedges are hubs or cut into pieces
   int32_t n_mat = 0;
   int32_t n_split = 0;    // vertices cut into pieces (panel rows that write partial sums)
+  bool invalid = false;   // slot_chunk schedule that does not fit (a vertex's sub-slots exceed a panel): discard
   std::vector<FPanel> panels;
   std::vector<int32_t> soff, pmem, slot_eid;
   // panel rows: vertex id, or 0x80000000 | partial slot for a piece of a split vertex
@@ -161,6 +162,13 @@ struct Opts {
   int32_t flags = 0;
   int32_t t_big = 8;           // fused: recompute hyperedges of at most this many members
   int32_t fused_tile_bytes = 16384;  // fused: LDS tile budget -> hyperedge slots per panel
+  bool fused_tile_auto = true;       // not set by the caller: a launch-bound graph may get smaller panels
+  // > 0 (set by the plan for launch-bound graphs only): nothing is materialised; a hyperedge with more
+  // members than this is cut into sub-slots of at most this many members, every one a slot of its own that
+  // the hyperedge's vertices all add -- the longest dependent gather chain of a panel is one chunk, and
+  // the aggregation stays one launch.  At least t_big, so hyperedges the default schedule recomputes
+  // whole keep their summation order.
+  int32_t slot_chunk = 0;
   int32_t fused_steps = 0;           // fused: stream entries per lane group and panel (0: 4 per slot on average)
   // hub pass (not in the C ABI; the host tests lower them to reach that code on small graphs)
   int64_t hub_min_nnz = 1 << 20;  // smaller graphs are launch-bound: no extra pass

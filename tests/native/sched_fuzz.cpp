@@ -23,7 +23,7 @@
 // (entry streams, tiles, 16-bit pair lists, register rows, partial rows per workgroup), panel records
 // (piece rows with bit 31), fixups (first level, then final) -- on exact integer "features", and
 // compare with Y = H H^T X computed directly.  Every vertex row must be written exactly once.
-static long g_hub_graphs = 0, g_hub_rounds = 0, g_hub_parts = 0, g_split_rows = 0, g_l1_fixups = 0, g_heavy = 0;
+static long g_chunked = 0, g_hub_graphs = 0, g_hub_rounds = 0, g_hub_parts = 0, g_split_rows = 0, g_l1_fixups = 0, g_heavy = 0;
 
 static void emulate_fused(const hg::FusedSched &f, int N, int M, const std::vector<int32_t> &ptr,
                           const std::vector<int32_t> &ind, const std::vector<int32_t> &ptr_v,
@@ -251,9 +251,12 @@ static void one_graph(std::mt19937 &rng, int N, int M, double mean, int hub_ever
       for (const auto &fx : s.fixups) CHECK(fx.first >= 0 && fx.count >= 1 && fx.first + fx.count <= s.nslots && fx.pad <= s.nslots);
     }
     for (int cap : {16, 64, 128}) {
-      for (int hubs = 0; hubs < 2; hubs++) {
+      for (int hubs = 0; hubs < 3; hubs++) {
         hg::Opts oh = o;
-        if (hubs) {  // reach the hub pass on these small graphs
+        if (hubs == 2) {  // launch-bound schedules: nothing materialised, long hyperedges cut into sub-slots
+          oh.flags |= HG_PLAN_NO_HUB_PASS;
+          oh.slot_chunk = variant == 1 ? 2 : 8;
+        } else if (hubs) {  // reach the hub pass on these small graphs
           oh.hub_min_nnz = 0;
           oh.hub_min_deg = 2;
           if (cap != 64) oh.hub_tile_bytes = 16384;  // 32-slot rounds: many rounds, many workgroups
@@ -264,6 +267,13 @@ static void one_graph(std::mt19937 &rng, int N, int M, double mean, int hub_ever
         // 8 lanes x 4 floats per row, as F = 32; or (small hub tiles) 32 lanes x 4 floats, as F = 128
         const int ng = (hubs && cap != 64) ? 8 : 32, row_floats = (hubs && cap != 64) ? 128 : 32;
         hg::build_fused(N, M, ptr.data(), ind.data(), ptr_v.data(), ind_v.data(), oh, cap, cap * 4, ng, row_floats, true, f);
+        if (hubs == 2) {
+          if (f.invalid) continue;  // a vertex's sub-slots exceed a panel: the plan discards such a schedule
+          CHECK(f.n_mat == 0 && f.n_split == 0 && f.fixups.empty());
+          emulate_fused(f, N, M, ptr, ind, ptr_v, ind_v, rng);
+          g_chunked++;
+          continue;
+        }
         int64_t n_mat = 0, n_big = 0;
         hg::classify_fused(N, M, ptr.data(), ptr_v.data(), ind_v.data(), oh, cap, cap * 4, &n_mat, &n_big);
         CHECK(n_mat == f.n_mat && n_big == f.n_split + f.hub.K);
@@ -330,7 +340,7 @@ int main(int argc, char **argv) {
   // the random graphs must actually have reached the hub pass, hub parts, split rows and two-level fixups
   std::printf("hub schedules %ld, hub rounds %ld, heavy hubs %ld, extra hub parts %ld, split vertices %ld, first-level fixups %ld\n",
               g_hub_graphs, g_hub_rounds, g_heavy, g_hub_parts, g_split_rows, g_l1_fixups);
-  CHECK(g_heavy > 50 && g_hub_graphs > 50 && g_hub_rounds > 10 * g_hub_graphs && g_hub_parts > 0 && g_split_rows > 100 && g_l1_fixups > 0);
+  CHECK(g_chunked > 200 && g_heavy > 50 && g_hub_graphs > 50 && g_hub_rounds > 10 * g_hub_graphs && g_hub_parts > 0 && g_split_rows > 100 && g_l1_fixups > 0);
   std::puts("sched_fuzz ok");
   return 0;
 }

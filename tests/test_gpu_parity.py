@@ -280,7 +280,16 @@ def test_plan_cache_and_streams(hg, oracle):
     with torch.cuda.stream(s):
         y = p1.aggregate(ptr, ind, x)
     s.synchronize()
-    assert np.array_equal(y.cpu().numpy(), ref)
+    y = y.cpu().numpy()
+    _assert_close(y, ref)
+    # A launch-bound graph's plan may cut hyperedges of more than 8 members into sub-slots (one launch, short
+    # gather chains): those sums are chunk-wise.  Every vertex whose hyperedges all have at most 8 members
+    # still reproduces the CPU order bit for bit.
+    esz = np.diff(inc.csrptr)
+    long_e = np.concatenate([(esz > 8)[H_ind].astype(np.int64), [0]])
+    touches_long = np.add.reduceat(long_e, np.minimum(H_ptr[:-1], inc.nnz))[:inc.N] * (np.diff(H_ptr) > 0)
+    assert (touches_long == 0).sum() > inc.N // 2
+    assert np.array_equal(y[touches_long == 0], ref[touches_long == 0])
 
 
 @pytest.mark.parametrize("F,K", [(32, 256), (64, 64)])
