@@ -322,3 +322,25 @@ def test_auto_variant_decision_is_cached(hg):
         assert plan.auto_variant(32) == first
     per_call = (time.perf_counter() - t0) / 200
     assert per_call < 50e-6, "auto variant costs %.1f us per call" % (per_call * 1e6)
+
+
+def test_launch_bound_graphs_get_small_panels_and_sub_slots(hg):
+    """One dataset-sized hypergraph is launch-bound: the plan sizes its panels for that (more, shorter
+    workgroups) and cuts long hyperedges into sub-slots instead of materialising them (one launch);
+    a batch in the throughput regime, or a caller who fixes the tile, keeps the 16 KB tile."""
+    from hypergef_amd import plan as planmod
+    host = planmod.make_opts(host_only=True)
+    cora = synth.cora_shape()
+    one = planmod.Plan.from_host(cora.N, cora.M, cora.csrptr, cora.colind, host).prepare(32)
+    assert one["cap"] < 128 and one["panels"] > 50 and one["n_mat"] == 0 and one["fixups"] == 0
+    fixed = planmod.Plan.from_host(cora.N, cora.M, cora.csrptr, cora.colind,
+                                   planmod.make_opts(host_only=True, fused_tile_bytes=16384)).prepare(32)
+    assert fixed["cap"] == 128
+    batch = synth.replicate_block_diagonal(cora, 64)
+    assert planmod.Plan.from_host(batch.N, batch.M, batch.csrptr, batch.colind, host).prepare(32)["cap"] == 128
+    cs = synth.citeseer_shape()  # hyperedges of up to 26 members
+    p = planmod.Plan.from_host(cs.N, cs.M, cs.csrptr, cs.colind, host)
+    info = p.prepare(32)
+    assert info["n_mat"] == 0 and info["fixups"] == 0 and p.auto_variant(32) == "fused"
+    assert info["slots"] > planmod.Plan.from_host(cs.N, cs.M, cs.csrptr, cs.colind,
+                                                  planmod.make_opts(host_only=True, fused_tile_bytes=16384)).prepare(32)["slots"] // 2
