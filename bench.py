@@ -65,12 +65,13 @@ def parse():
     p.add_argument("--tile-bytes", type=int, default=0)
     p.add_argument("--fused-steps", type=int, default=0)
     p.add_argument("--no-hub-pass", action="store_true")
+    p.add_argument("--no-row-stream", action="store_true")
     p.add_argument("--weighted", action="store_true", help="hgnnaggr (degE, degV, W) instead of H H^T X")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-parity", action="store_true", help="skip the oracle comparison of the timed output")
     p.add_argument("--no-extras", action="store_true", help="skip device-copy / single-graph / sharded extras")
     p.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs (N = 1)")
-    p.add_argument("--config-steps", type=int, default=50)
+    p.add_argument("--config-steps", type=int, default=100)
     p.add_argument("--short-max", type=int, default=0)
     p.add_argument("--panel-rows", type=int, default=0)
     p.add_argument("--panel-nnz", type=int, default=0)
@@ -409,7 +410,8 @@ def main():
 
     opts_kw = dict(short_max=args.short_max, panel_rows=args.panel_rows, panel_nnz=args.panel_nnz,
                    xcd_remap=not args.no_xcd_remap, t_big=args.t_big, fused_tile_bytes=args.tile_bytes,
-                   fused_steps=args.fused_steps, hub_pass=not args.no_hub_pass)
+                   fused_steps=args.fused_steps, hub_pass=not args.no_hub_pass,
+                   row_stream=not args.no_row_stream)
     F = args.feat
     one = world == 1
     res, cpu, st = run_config(args.shape, args.replicas, F, args.weighted, args.variant, args.steps, args.warmup,
@@ -469,7 +471,7 @@ def main():
             if (shape, reps, feat, weighted) == (args.shape, args.replicas, F, args.weighted):
                 continue
             try:
-                r, c, s2 = run_config(shape, reps, feat, weighted, "auto", args.config_steps, 5, dev, sync, barrier,
+                r, c, s2 = run_config(shape, reps, feat, weighted, "auto", args.config_steps, 10, dev, sync, barrier,
                                       rank, dict(xcd_remap=True), want_cpu=False, want_parity=not args.no_parity)
                 del s2
                 torch.cuda.empty_cache()

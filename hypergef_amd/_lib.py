@@ -19,6 +19,7 @@ HG_PLAN_HOST_ONLY = 1
 HG_PLAN_NO_XCD_REMAP = 2
 HG_PLAN_DFS_ORDER = 4
 HG_PLAN_NO_HUB_PASS = 8
+HG_PLAN_NO_ROW_STREAM = 16
 
 VARIANTS = {"auto": HG_VARIANT_AUTO, "pull": HG_VARIANT_PULL, "push_atomic": HG_VARIANT_PUSH_ATOMIC,
             "fused": HG_VARIANT_FUSED}

@@ -114,13 +114,17 @@ int fused_upload(hg::FusedSched &f, int64_t &bytes) {
   UP(hub.rec, hub.d_rec);
   UP(hub.rec_tab, hub.d_rec_tab);
   UP(hub.wg_first, hub.d_wg_first);
+  UP(mat_stream.rec, mat_stream.d_rec);
+  UP(mat_stream.rec_tab, mat_stream.d_rec_tab);
+  UP(mat_stream.fixups, mat_stream.d_fixups);
 #undef UP
   return sched_upload(f.mat_sched, bytes);
 }
 
 void fused_free(hg::FusedSched &f) {
   void *ptrs[] = {f.d_prow, f.d_mat_ptr, f.d_mat_ind, f.d_mat_eid, f.d_rec, f.d_rec_tab, f.d_eid_all, f.d_bsA,
-                  f.d_bsB, f.d_bsD, f.d_fixups, f.hub.d_vslot0, f.hub.d_rec, f.hub.d_rec_tab, f.hub.d_wg_first};
+                  f.d_bsB, f.d_bsD, f.d_fixups, f.hub.d_vslot0, f.hub.d_rec, f.hub.d_rec_tab, f.hub.d_wg_first, f.mat_stream.d_rec, f.mat_stream.d_rec_tab,
+                  f.mat_stream.d_fixups};
   for (void *q : ptrs)
     if (q) (void)hipFree(q);
   sched_free(f.mat_sched);
@@ -250,7 +254,7 @@ Carve carve(const hg_plan *p, int32_t F) {
   size_t off = round256((size_t)p->M * F * sizeof(float));
   for (int h = 0; h < 2; h++) {
     c.part[h] = off;
-    off += round256((size_t)p->sched[h].nslots * F * sizeof(float));
+    off += round256((size_t)std::max(p->sched[h].nslots, p->stream_nslots[h]) * F * sizeof(float));
   }
   c.total = off;
   return c;
@@ -261,7 +265,7 @@ struct FusedCarve {
 FusedCarve fused_carve(const hg::FusedSched &f, int32_t F) {
   FusedCarve c;
   c.mat_part = round256((size_t)f.n_mat * F * sizeof(float));
-  c.part = c.mat_part + round256((size_t)f.mat_sched.nslots * F * sizeof(float));
+  c.part = c.mat_part + round256((size_t)std::max(f.mat_sched.nslots, f.mat_stream.nslots) * F * sizeof(float));
   c.total = c.part + round256((size_t)f.n_part * F * sizeof(float));
   return c;
 }
@@ -284,6 +288,7 @@ size_t workspace_need(const hg_plan *cp, int32_t F) {
 // table (yelp, the power-law config): the fused path is then the pull path plus overhead.
 int pick_variant_uncached(const hg_plan *plan, int32_t F, bool vec4, int32_t *variant,
                           const hg::FusedSched **f);
+int get_row_stream(const hg_plan *cp, int hop, int32_t ng, const hg::RowStream **out);
 
 int pick_variant(const hg_plan *plan, int32_t F, bool vec4, int32_t *variant,
                  const hg::FusedSched **f) {
@@ -370,9 +375,72 @@ int run_sched(const hg_plan *p, const hg::Sched &s, int32_t F, const int32_t *pt
   return HG_OK;
 }
 
+// The pull hops on the streaming row gather where it applies (16-byte lanes, buffer-addressable table):
+// the schedule for this hop and lane layout, built and uploaded on first use.
+int get_row_stream(const hg_plan *cp, int hop, int32_t ng, const hg::RowStream **out) {
+  hg_plan *p = const_cast<hg_plan *>(cp);
+  std::lock_guard<std::mutex> lock(p->stream_mu);
+  const int64_t key = (int64_t)hop * 1024 + ng;
+  auto it = p->row_streams.find(key);
+  if (it == p->row_streams.end()) {
+    hg::RowStream rs;
+    try {
+      if (hop == 0) hg::build_row_stream(p->M, p->ptr_t.data(), p->ind_t.data(), nullptr, ng, p->N, rs);
+      else hg::build_row_stream(p->N, p->ptr_v.data(), p->ind_v.data(), nullptr, ng, p->M, rs);
+    } catch (const std::bad_alloc &) {
+      hg::set_error("row stream schedule: host allocation failed");
+      return HG_ERR_NOMEM;
+    }
+    if (rs.nslots > p->stream_nslots[hop]) {
+      hg::set_error("row stream schedule: internal error, more partial rows than the workspace layout reserves");
+      return HG_ERR_INVALID;
+    }
+    int rc;
+    if ((rc = upload(rs.rec, &rs.d_rec, p->device_bytes)) != HG_OK) return rc;
+    if ((rc = upload(rs.rec_tab, &rs.d_rec_tab, p->device_bytes)) != HG_OK) return rc;
+    if ((rc = upload(rs.fixups, &rs.d_fixups, p->device_bytes)) != HG_OK) return rc;
+    it = p->row_streams.emplace(key, std::move(rs)).first;
+  }
+  *out = &it->second;
+  return HG_OK;
+}
+
 int run_hop(const hg_plan *p, int hop, int32_t F, const int32_t *ptr, const int32_t *ind,
             const float *src, const float *scaleA, const float *scaleB, float *dst,
             float *partial, hipStream_t stream) {
+  const bool vec4 = (F % 4 == 0) && aligned16(src) && aligned16(dst) && aligned16(partial);
+  const int64_t nsrc = hop == 0 ? p->N : p->M, sb = nsrc * F * 4;
+  if (vec4 && nsrc < (1 << 24) && sb > 0 && sb < ((int64_t)1 << 31) && !(p->opts.flags & HG_PLAN_NO_ROW_STREAM)) {
+    const int32_t ng = 256 / (hg::fused_tile_row_floats(F, true) / 4);
+    const hg::RowStream *rs = nullptr;
+    int rc = get_row_stream(p, hop, ng, &rs);
+    if (rc != HG_OK) return rc;
+    hg::StreamArgs sa;
+    sa.rec = rs->d_rec;
+    sa.rec_tab = rs->d_rec_tab;
+    sa.nrec = (int32_t)rs->rec_tab.size();
+    sa.ng = rs->ng;
+    sa.cap = rs->cap;
+    sa.max_rec_words = rs->max_rec_words;
+    sa.src = src;
+    sa.src_bytes = (int32_t)sb;
+    sa.nrows_src = (int32_t)nsrc;
+    sa.scaleA = scaleA;
+    sa.scaleB = scaleB;
+    sa.dst = dst;
+    sa.partial = partial;
+    sa.F = F;
+    sa.xcd_remap = (p->opts.flags & HG_PLAN_NO_XCD_REMAP) ? 0 : 1;
+    if (sa.nrec == 0) return HG_OK;
+    if (hg::stream_rows_ok(sa, true)) {
+      hipError_t e = hg::launch_stream_rows(sa, stream);
+      if (e == hipSuccess)
+        e = hg::launch_fixups(rs->d_fixups, (int)rs->fixups.size(), rs->n_fix_l1, F, partial, dst, scaleA, scaleB,
+                              nullptr, true, stream);
+      if (e != hipSuccess) return hip_fail("stream_rows launch", e);
+      return HG_OK;
+    }
+  }
   return run_sched(p, p->sched[hop], F, ptr, ind, src, scaleA, scaleB, nullptr, nullptr, dst, partial,
                    stream);
 }
@@ -439,6 +507,23 @@ int plan_build(hg_plan **out, int32_t N, int32_t M, const int32_t *csrptr_t,
       if (len <= o.t_big) small += len;
     }
     p->small_nnz_frac = p->nnz > 0 ? (double)small / (double)p->nnz : 0.0;
+    for (int h = 0; h < 2; h++) {  // partial rows of the streaming row gather: chunks of rows beyond kRowStreamChunk,
+      const std::vector<int32_t> &ptr = h ? p->ptr_v : p->ptr_t;  // plus the first-level sums of rows in more than 32 chunks
+      int64_t ns = 0;
+      for (size_t r = 0; r + 1 < ptr.size(); r++) {
+        const int64_t len = ptr[r + 1] - ptr[r];
+        if (len > hg::kRowStreamChunk) {
+          const int64_t k = (len + hg::kRowStreamChunk - 1) / hg::kRowStreamChunk;
+          ns += k;
+          if (k > 32) {
+            int64_t fan = 1;
+            while (fan * fan < k) fan++;
+            ns += (k + fan - 1) / fan;
+          }
+        }
+      }
+      p->stream_nslots[h] = (int32_t)std::min<int64_t>(ns, 0x7fffffff);
+    }
   } catch (const std::bad_alloc &) {
     delete p;
     hg::set_error("hg_plan_create: host allocation failed");
@@ -499,6 +584,11 @@ void hg_plan_destroy(hg_plan *p) {
   if (p->d_ind_v) (void)hipFree(p->d_ind_v);
   for (int h = 0; h < 2; h++) sched_free(p->sched[h]);
   for (auto &kv : p->fused) fused_free(kv.second);
+  for (auto &kv : p->row_streams) {
+    void *ptrs[] = {kv.second.d_rec, kv.second.d_rec_tab, kv.second.d_fixups};
+    for (void *q : ptrs)
+      if (q) (void)hipFree(q);
+  }
   delete p;
 }
 
@@ -628,6 +718,17 @@ int hg_plan_prepare(const hg_plan *p, int32_t F, hg_fused_info *info) {
   const hg::FusedSched *f = nullptr;
   int rc = get_fused(p, F, F % 4 == 0, &f);
   if (rc != HG_OK) return rc;
+  // the pull variant's schedules for this lane layout too: after hg_plan_prepare a call of any variant
+  // allocates nothing
+  if (!(p->opts.flags & (HG_PLAN_HOST_ONLY | HG_PLAN_NO_ROW_STREAM)) && F % 4 == 0) {
+    const int32_t ng = 256 / (hg::fused_tile_row_floats(F, true) / 4);
+    for (int hop = 0; hop < 2; hop++) {
+      const int64_t nsrc = hop == 0 ? p->N : p->M;
+      if (nsrc >= (1 << 24) || nsrc * F * 4 >= ((int64_t)1 << 31)) continue;
+      const hg::RowStream *rs = nullptr;
+      if ((rc = get_row_stream(p, hop, ng, &rs)) != HG_OK) return rc;
+    }
+  }
   if (info) {
     info->cap = f->cap;
     info->t_big = f->t_big;
@@ -805,9 +906,33 @@ static int aggr_impl(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
     const int32_t mat_bytes = mb < ((int64_t)1 << 31) ? (int32_t)mb : 0;
     // (a) materialised hyperedges (more than t_big members): Xe_mat rows
     if (f->n_mat > 0) {
-      rc = run_sched(plan, f->mat_sched, F, f->d_mat_ptr, f->d_mat_ind, X, degE, W, f->d_mat_eid,
-                     nullptr, Xe, reinterpret_cast<float *>(ws + fc.mat_part), s);
-      if (rc != HG_OK) return rc;
+      hg::StreamArgs sa;
+      sa.rec = f->mat_stream.d_rec;
+      sa.rec_tab = f->mat_stream.d_rec_tab;
+      sa.nrec = (int32_t)f->mat_stream.rec_tab.size();
+      sa.ng = f->mat_stream.ng;
+      sa.cap = f->mat_stream.cap;
+      sa.max_rec_words = f->mat_stream.max_rec_words;
+      sa.src = X;
+      sa.src_bytes = x_bytes;
+      sa.nrows_src = plan->N;
+      sa.scaleA = degE;
+      sa.scaleB = W;
+      sa.dst = Xe;
+      sa.partial = reinterpret_cast<float *>(ws + fc.mat_part);
+      sa.F = F;
+      sa.xcd_remap = (plan->opts.flags & HG_PLAN_NO_XCD_REMAP) ? 0 : 1;
+      if (hg::stream_rows_ok(sa, vec4)) {  // the streaming row gather; else the general kernel
+        hipError_t e = hg::launch_stream_rows(sa, s);
+        if (e == hipSuccess)
+          e = hg::launch_fixups(f->mat_stream.d_fixups, (int)f->mat_stream.fixups.size(), f->mat_stream.n_fix_l1, F,
+                                sa.partial, Xe, degE, W, f->d_mat_eid, vec4, s);
+        if (e != hipSuccess) return hip_fail("stream_rows launch", e);
+      } else {
+        rc = run_sched(plan, f->mat_sched, F, f->d_mat_ptr, f->d_mat_ind, X, degE, W, f->d_mat_eid,
+                       nullptr, Xe, reinterpret_cast<float *>(ws + fc.mat_part), s);
+        if (rc != HG_OK) return rc;
+      }
     }
     // (b) register hubs: persistent workgroups stream the hyperedges, running sums in registers
     if (f->hub.K > 0) {
@@ -877,7 +1002,7 @@ static int aggr_impl(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
     if (e != hipSuccess) return hip_fail("fused_panel launch", e);
     // (d) hubs and split vertices: Y[v] = degV[v] * (sum of the vertex's partial rows), fixed order
     if (!f->fixups.empty()) {
-      e = hg::launch_fixups(f->d_fixups, (int)f->fixups.size(), f->n_fix_l1, F, partial, Y, degV, vec4, s);
+      e = hg::launch_fixups(f->d_fixups, (int)f->fixups.size(), f->n_fix_l1, F, partial, Y, degV, nullptr, nullptr, vec4, s);
       if (e != hipSuccess) return hip_fail("fixup launch", e);
     }
     return HG_OK;

@@ -156,6 +156,7 @@ void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_
       f.mat_ptr.push_back((int32_t)f.mat_ind.size());
     }
   build_sched(f.n_mat, f.mat_ptr.data(), o, f.mat_sched);
+  if (allow_hub) build_row_stream(f.n_mat, f.mat_ptr.data(), f.mat_ind.data(), f.mat_eid.data(), ng, N, f.mat_stream);
 
   // ---- vertices that do not fit a panel: register hubs, or pieces ------------------------------
   // big[v]: 1 = register hub, 2 = split into pieces
@@ -583,6 +584,89 @@ static void build_hub_pass(int32_t N, int32_t M, const int32_t *ptr_t, const int
     f.n_part += parts[h] * hp.nwg;
     add_fixups(hp.vid[h], base, parts[h] * hp.nwg, f.n_part, f.fixups, finals);
   }
+}
+
+
+void build_row_stream(int32_t nrows, const int32_t *ptr, const int32_t *ind, const int32_t *scale_index,
+                      int32_t ng, int32_t idle, RowStream &rs) {
+  rs = RowStream();
+  rs.ng = ng;
+  // A lane group walks at most kRowStreamChunk entries for one row, and a workgroup's record holds 64 steps'
+  // worth of entries: with shorter records a single 64-entry row sets the step count of a record whose
+  // other lane groups hold a quarter of that (power-law config, materialisation of 375 k rows: 258 us with
+  // 16-step records, 136 us with 64-step ones; chunks of 32 or 128: 137 / 149 us).
+  constexpr int32_t kChunk = kRowStreamChunk;
+  const int32_t ent_cap = 64 * ng;
+  rs.cap = 4 * ng;                    // rows (or chunks) per workgroup
+  struct Unit {
+    int32_t m0, m1, dst, sidx;
+  };
+  std::vector<Unit> units;
+  std::vector<int32_t> mem;
+  std::vector<Fixup> finals;
+  auto flush = [&]() {
+    if (units.empty()) return;
+    const int32_t ns = (int32_t)units.size();
+    std::vector<SlotRange> sr((size_t)ns);
+    for (int32_t k = 0; k < ns; k++) sr[k] = SlotRange{units[k].m0, units[k].m1, 0u};
+    PackedStream ps;
+    pack_stream(sr, mem.data(), ng, idle, idle, 0x3fffffffu, ps);
+    const int32_t hdr = 8;
+    const int32_t off_gbase = hdr, off_stream = off_gbase + ng, off_dst = off_stream + ps.steps * ng;
+    const int32_t off_sidx = off_dst + ns;
+    const int32_t words = (off_sidx + ns + 3) & ~3;
+    SRec rt;
+    rt.off = (int64_t)rs.rec.size();
+    rt.len = words;
+    rt.nslots = ns;
+    rt.off_sidx = off_sidx;
+    rt.pad = 0;
+    rs.rec_tab.push_back(rt);
+    rs.max_rec_words = std::max(rs.max_rec_words, words);
+    rs.max_steps = std::max(rs.max_steps, ps.steps);
+    rs.entries += (int64_t)ps.steps * ng;
+    const size_t base = rs.rec.size();
+    rs.rec.resize(base + (size_t)words, 0);
+    int32_t *r = rs.rec.data() + base;
+    r[0] = ps.steps;
+    r[1] = ns;
+    r[4] = off_gbase;
+    r[5] = off_stream;
+    r[6] = off_dst;
+    r[7] = off_sidx;
+    for (int32_t g = 0; g < ng; g++) r[off_gbase + g] = ps.gslots[g];
+    std::copy(ps.stream.begin(), ps.stream.end(), r + off_stream);
+    for (int32_t k = 0; k < ns; k++) {
+      r[off_dst + ps.newid[k]] = units[k].dst;
+      r[off_sidx + ps.newid[k]] = units[k].sidx;
+    }
+    units.clear();
+    mem.clear();
+  };
+  auto add_unit = [&](int32_t b, int32_t e, int32_t dst, int32_t sidx) {
+    const int32_t n = std::max(1, e - b);
+    if (!units.empty() && ((int32_t)units.size() == rs.cap || (int32_t)mem.size() + n > ent_cap)) flush();
+    const int32_t m0 = (int32_t)mem.size();
+    if (e > b) mem.insert(mem.end(), ind + b, ind + e);
+    else mem.push_back(idle);  // an empty row: one idle entry (zeros) that carries the last flag
+    units.push_back(Unit{m0, (int32_t)mem.size(), dst, sidx});
+  };
+  for (int32_t r = 0; r < nrows; r++) {
+    const int32_t len = ptr[r + 1] - ptr[r];
+    const int32_t si = scale_index ? scale_index[r] : r;
+    if (len <= kChunk) {
+      add_unit(ptr[r], ptr[r + 1], r, len > 0 ? si : -1);  // an empty row stays exactly 0 (its scale may be inf)
+    } else {
+      const int32_t k = (len + kChunk - 1) / kChunk, first = rs.nslots;
+      for (int32_t c = 0; c < k; c++)
+        add_unit(ptr[r] + c * kChunk, std::min(ptr[r] + (c + 1) * kChunk, ptr[r + 1]),
+                 (int32_t)(0x80000000u | (uint32_t)(rs.nslots++)), -1);
+      add_fixups(r, first, k, rs.nslots, rs.fixups, finals);
+    }
+  }
+  flush();
+  rs.n_fix_l1 = (int32_t)rs.fixups.size();
+  rs.fixups.insert(rs.fixups.end(), finals.begin(), finals.end());
 }
 
 // One self-contained int32 record per panel for the packed kernel: a header, the

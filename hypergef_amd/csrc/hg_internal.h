@@ -107,6 +107,35 @@ struct HubPass {
   HubRec *d_rec_tab = nullptr;
 };
 
+// ---- streaming row gather (materialisation pre-pass) ----------------------------------------------
+// dst[r] = scaleB * (scaleA * sum of src rows listed in CSR row r), as gather_rows_kernel computes it, but
+// scheduled like a panel's hop 1: a workgroup's rows are spread over the lane groups longest first, every
+// group walks the same number of steps with unpredicated buffer loads, and the lane group that finishes a
+// row scales and stores it straight from registers -- no tile, no second hop.  Rows of more than
+// `chunk` entries are cut into chunks that leave partial rows (summed by fixups, two levels above 32).
+// Record: [0] steps [1] nslots [4] off_gbase [5] off_stream [6] off_dst [7] off_sidx, then gbase[ng],
+// stream[steps * ng] (entry words as in a panel record; an empty row is one idle entry with the last
+// flag), dst[nslots] (output row, or bit 31 | partial row), sidx[nslots] (index of the row's scale
+// factors, -1 = none: chunks and empty rows).
+constexpr int kRowStreamChunk = 64;  // rows longer than this are cut into chunks (partial rows + fixups)
+
+struct SRec {
+  int64_t off;
+  int32_t len, nslots, off_sidx, pad;
+};
+struct RowStream {
+  int32_t ng = 0, cap = 0, max_rec_words = 0, max_steps = 0;
+  int32_t nslots = 0;  // partial rows
+  int64_t entries = 0;
+  std::vector<int32_t> rec;
+  std::vector<SRec> rec_tab;
+  std::vector<Fixup> fixups;  // rows = output rows; first-level ones first
+  int32_t n_fix_l1 = 0;
+  int32_t *d_rec = nullptr;
+  SRec *d_rec_tab = nullptr;
+  Fixup *d_fixups = nullptr;
+};
+
 struct FusedSched {
   int32_t cap = 0;        // slots per panel (LDS tile rows)
   int32_t rows_cap = 0;   // rows per panel
@@ -125,6 +154,7 @@ struct FusedSched {
   // materialised hyperedges (compact CSR over their members)
   std::vector<int32_t> mat_ptr, mat_ind, mat_eid;
   Sched mat_sched;
+  RowStream mat_stream;  // the same rows for stream_rows_kernel (buffer-addressable tables, 16-byte lanes)
   HubPass hub;
   // partial rows of the fused path: [hub: sum over hubs of parts * nwg][pieces][first-level sums]
   int32_t n_part = 0;
@@ -195,6 +225,10 @@ void classify_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *p
 void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_t,
                  const int32_t *ptr_v, const int32_t *ind_v, const Opts &o, int32_t cap,
                  int32_t mem_cap, int32_t ng, int32_t row_floats, bool allow_hub, FusedSched &f);
+// rows [0, nrows) of the CSR (ptr, ind) as a RowStream; scale_index[r] (or r itself if null) names the
+// row's scale factors; idle = rows of the gathered table
+void build_row_stream(int32_t nrows, const int32_t *ptr, const int32_t *ind, const int32_t *scale_index,
+                      int32_t ng, int32_t idle, RowStream &rs);
 // the two-level fixup rule shared by build_sched and build_fused
 void add_fixups(int32_t row, int32_t first, int32_t count, int32_t &nslots, std::vector<Fixup> &level1,
                 std::vector<Fixup> &finals);
@@ -212,6 +246,10 @@ struct hg_plan {
   std::map<int64_t, hg::FusedSched> fused;  // keyed by (slot, entry) capacity: depends on F
   std::map<int64_t, const hg::FusedSched *> fused_by_width;  // (F, vec4) -> the schedule built for it
   std::mutex fused_mu;
+  // pull variant on the streaming row gather: schedules per (hop, lane groups), built on first use
+  std::map<int64_t, hg::RowStream> row_streams;
+  std::mutex stream_mu;
+  int32_t stream_nslots[2] = {0, 0};  // partial rows a RowStream of each hop needs (independent of the lane layout)
   std::map<int64_t, int32_t> auto_choice;  // what HG_VARIANT_AUTO resolved to, keyed by (F, vec4)
   std::mutex auto_mu;
   double small_nnz_frac = 0.0;  // share of incidences in hyperedges of <= t_big members

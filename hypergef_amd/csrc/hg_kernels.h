@@ -90,6 +90,18 @@ struct HubArgs {
   int32_t debug = 0;    // ablation bits, diagnostic build only
 };
 
+// stream_rows_kernel (RowStream, hg_internal.h)
+struct StreamArgs {
+  const int32_t *rec;
+  const SRec *rec_tab;
+  int32_t nrec, ng, cap, max_rec_words;
+  const float *src;             // gathered table [nrows_src, F]
+  int32_t src_bytes, nrows_src;
+  const float *scaleA, *scaleB; // indexed by the record's sidx lists, or null
+  float *dst, *partial;
+  int32_t F, xcd_remap;
+};
+
 struct PushArgs {
   int64_t n_group;
   const int32_t *group_key, *group_row, *group_st, *group_ed;
@@ -106,7 +118,10 @@ hipError_t launch_hub_pass(const HubArgs &a, bool vec4, hipStream_t stream);
 size_t hub_pass_lds_bytes(int32_t cap, int32_t row_floats, int32_t max_rec_words);
 // Y[fx.row] = scale[fx.row] * (sum of the fixup's partial rows); first-level fixups first
 hipError_t launch_fixups(const Fixup *fixups, int nfix, int nfix_l1, int32_t F, float *partial, float *Y,
-                         const float *scale, bool vec4, hipStream_t stream);
+                         const float *scaleA, const float *scaleB, const int32_t *scale_map, bool vec4,
+                         hipStream_t stream);
+bool stream_rows_ok(const StreamArgs &a, bool vec4);  // buffer-addressable table, 16-byte lanes
+hipError_t launch_stream_rows(const StreamArgs &a, hipStream_t stream);
 bool fused_linear_ok(const FusedArgs &a);  // can launch_fused run this call's linear epilogue?
 hipError_t launch_linear(const LinearArgs &a, hipStream_t stream);
 int wgrad_parts(int64_t nrows, int32_t Fa, int32_t Fb);

@@ -1053,6 +1053,83 @@ __global__ __launch_bounds__(1024) void hub_pass_kernel(const HubArgs a) {
   }
 }
 
+// Streaming row gather (RowStream, hg_internal.h): dst[r] = scaleB * (scaleA * sum of the src rows of CSR
+// row r), scheduled like a panel's hop 1 -- the workgroup's rows spread over the lane groups longest first,
+// eight unpredicated buffer loads in flight per lane -- and finished in registers: the lane group that
+// reaches a row's last entry scales the sum and stores the row (or a chunk's partial row).  No tile, no
+// second hop, one barrier.  The materialisation pre-pass of the fused variant runs on it.
+template <int LPR, int VEC, int U>
+__global__ __launch_bounds__(256) void stream_rows_kernel(const StreamArgs a) {
+  constexpr int BS = 256, NG = BS / LPR, TW = LPR * VEC;
+  using V = Vec<VEC>;
+  extern __shared__ int32_t smem[];
+  const int tid = threadIdx.x;
+  const int gl = tid & (LPR - 1);
+  const int col = blockIdx.y * TW + gl * VEC;
+  const bool col_ok = col < a.F;
+  const int64_t F = a.F;
+  int b = blockIdx.x;
+  if (a.xcd_remap) {
+    const int x = b & 7, i = b >> 3;
+    const int cpx = a.nrec >> 3, rem = a.nrec & 7;
+    b = x * cpx + (x < rem ? x : rem) + i;
+  }
+  const SRec rt = a.rec_tab[b];
+  const int32_t *grec = a.rec + rt.off;
+  int32_t *rec = smem;                                           // [max_rec_words]
+  float *sA = reinterpret_cast<float *>(rec + a.max_rec_words);  // [cap]
+  float *sB = sA + a.cap;                                        // [cap]
+  for (int i = tid; i < (rt.len >> 2); i += BS)
+    reinterpret_cast<hg_i4 *>(rec)[i] = reinterpret_cast<const hg_i4 *>(grec)[i];
+  if (a.scaleA || a.scaleB)
+    for (int i = tid; i < rt.nslots; i += BS) {
+      const int si = grec[rt.off_sidx + i];  // -1: a chunk (scaled by its fixup) or an empty row (stays exactly 0)
+      sA[i] = (a.scaleA && si >= 0) ? a.scaleA[si] : 1.f;
+      sB[i] = (a.scaleB && si >= 0) ? a.scaleB[si] : 1.f;
+    }
+  __syncthreads();
+  const int steps = rec[0];
+  const int32_t *stream = rec + rec[5];
+  const int32_t *dstl = rec + rec[6];
+  const int g = tid / LPR;
+  int slot = rec[rec[4] + g];
+  const unsigned row_bytes = (unsigned)a.F * 4u;
+  const unsigned col_off = col_ok ? (unsigned)col * 4u : 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.src), 0, a.src_bytes, 0x00020000);
+  const int idle = a.nrows_src;
+  V acc = V::zero();
+  auto block = [&](const int s0, auto full) {
+    constexpr bool FULL = decltype(full)::value;
+    int ent[U];
+#pragma unroll
+    for (int j = 0; j < U; j++) ent[j] = (FULL || s0 + j < steps) ? stream[(s0 + j) * NG + g] : idle;
+    V v[U];
+#pragma unroll
+    for (int j = 0; j < U; j++) {
+      if (!FULL && s0 + j >= steps) {
+        v[j] = V::zero();
+        continue;
+      }
+      v[j] = V::load_buf(rx, __umul24((unsigned)ent[j], row_bytes) + col_off);  // flags sit above bit 23
+    }
+#pragma unroll
+    for (int j = 0; j < U; j++) {
+      acc.add(v[j]);
+      if (ent[j] < 0) {  // bit 31: last entry of this row (or chunk)
+        if (a.scaleA) acc.mul(sA[slot]);
+        if (a.scaleB) acc.mul(sB[slot]);
+        const int d = dstl[slot];
+        slot++;
+        if (col_ok) acc.store((d < 0 ? a.partial + (int64_t)(d & 0x7fffffff) * F : a.dst + (int64_t)d * F) + col);
+        acc = V::zero();
+      }
+    }
+  };
+  int s0 = 0;
+  for (; s0 + U <= steps; s0 += U) block(s0, std::true_type{});
+  if (s0 < steps) block(s0, std::false_type{});
+}
+
 // The reference's register-fused scheme on wave64: LPR lanes = LPR feature
 // columns of one task, 64/LPR tasks per wave.  Gather-sum the read partition,
 // scale by degE*W, scatter acc*degV[v] to the write partition with hardware
@@ -1207,13 +1284,16 @@ hipError_t launch_gather(const GatherArgs &a, int nfix, int nfix_l1, const Fixup
 }
 
 hipError_t launch_fixups(const Fixup *fixups, int nfix, int nfix_l1, int32_t F, float *partial, float *Y,
-                         const float *scale, bool vec4, hipStream_t stream) {
+                         const float *scaleA, const float *scaleB, const int32_t *scale_map, bool vec4,
+                         hipStream_t stream) {
   if (nfix == 0) return hipSuccess;
   GatherArgs a{};
   a.F = F;
   a.partial = partial;
   a.dst = Y;
-  a.scaleA = scale;
+  a.scaleA = scaleA;
+  a.scaleB = scaleB;
+  a.scale_map = scale_map;
   const int lanes = vec4 ? F / 4 : F;
   const int lpr = std::min(64, next_pow2(std::max(lanes, 1)));
 #define HG_CASE(L) \
@@ -1229,6 +1309,34 @@ hipError_t launch_fixups(const Fixup *fixups, int nfix, int nfix_l1, int32_t F, 
     HG_CASE(64)
   }
 #undef HG_CASE
+  return hipErrorInvalidValue;
+}
+
+bool stream_rows_ok(const StreamArgs &a, bool vec4) {
+  return vec4 && a.nrec > 0 && a.src_bytes > 0 && a.nrows_src < (1 << 24) && a.F < (1 << 22) &&
+         a.ng == 256 / (fused_tile_row_floats(a.F, true) / 4) &&
+         (size_t)a.max_rec_words * 4 + (size_t)2 * a.cap * 4 <= kLdsMax;
+}
+
+template <int LPR>
+static hipError_t launch_stream_t(const StreamArgs &a, hipStream_t stream) {
+  constexpr int TW = LPR * 4;
+  const dim3 grid(a.nrec, (a.F + TW - 1) / TW);
+  const size_t lds = (size_t)a.max_rec_words * 4 + (size_t)2 * a.cap * 4;
+  return launch_lds<stream_rows_kernel<LPR, 4, 8>>(grid, lds, stream, a);
+}
+
+hipError_t launch_stream_rows(const StreamArgs &a, hipStream_t stream) {
+  if (a.nrec == 0) return hipSuccess;
+  switch (fused_tile_row_floats(a.F, true) / 4) {
+    case 1: return launch_stream_t<1>(a, stream);
+    case 2: return launch_stream_t<2>(a, stream);
+    case 4: return launch_stream_t<4>(a, stream);
+    case 8: return launch_stream_t<8>(a, stream);
+    case 16: return launch_stream_t<16>(a, stream);
+    case 32: return launch_stream_t<32>(a, stream);
+    case 64: return launch_stream_t<64>(a, stream);
+  }
   return hipErrorInvalidValue;
 }
 

@@ -28,12 +28,15 @@ def _stream_handle(device):
 
 
 def make_opts(short_max=0, split_len=0, panel_rows=0, panel_nnz=0, xcd_remap=True, host_only=False,
-              t_big=0, fused_tile_bytes=0, dfs_order=False, hub_pass=True, fused_steps=0):
+              t_big=0, fused_tile_bytes=0, dfs_order=False, hub_pass=True, fused_steps=0,
+              row_stream=True):
     flags = 0
     if dfs_order:
         flags |= _lib.HG_PLAN_DFS_ORDER
     if not hub_pass:
         flags |= _lib.HG_PLAN_NO_HUB_PASS
+    if not row_stream:
+        flags |= _lib.HG_PLAN_NO_ROW_STREAM
     if host_only:
         flags |= _lib.HG_PLAN_HOST_ONLY
     if not xcd_remap:

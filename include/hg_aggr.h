@@ -86,6 +86,7 @@ typedef struct hg_plan_opts {
 #define HG_PLAN_HOST_ONLY 1 /* build the schedule on the host, upload nothing (tests) */
 #define HG_PLAN_NO_XCD_REMAP 2 /* keep blockIdx -> panel identity mapping */
 #define HG_PLAN_DFS_ORDER 4 /* fused: panel rows in plain depth-first order (no greedy growth) */
+#define HG_PLAN_NO_ROW_STREAM 16 /* pull: always the general row-gather kernel (panels + wave tasks), never the streaming one */
 #define HG_PLAN_NO_HUB_PASS 8 /* fused: no register-hub pass; every vertex too big for a panel is cut into pieces */
 
 typedef struct hg_plan_info {

@@ -23,7 +23,7 @@
 // (entry streams, tiles, 16-bit pair lists, register rows, partial rows per workgroup), panel records
 // (piece rows with bit 31), fixups (first level, then final) -- on exact integer "features", and
 // compare with Y = H H^T X computed directly.  Every vertex row must be written exactly once.
-static long g_chunked = 0, g_hub_graphs = 0, g_hub_rounds = 0, g_hub_parts = 0, g_split_rows = 0, g_l1_fixups = 0, g_heavy = 0;
+static long g_stream_rows = 0, g_stream_chunks = 0, g_chunked = 0, g_hub_graphs = 0, g_hub_rounds = 0, g_hub_parts = 0, g_split_rows = 0, g_l1_fixups = 0, g_heavy = 0;
 
 static void emulate_fused(const hg::FusedSched &f, int N, int M, const std::vector<int32_t> &ptr,
                           const std::vector<int32_t> &ind, const std::vector<int32_t> &ptr_v,
@@ -40,6 +40,68 @@ static void emulate_fused(const hg::FusedSched &f, int N, int M, const std::vect
     CHECK(f.mat_eid[i] >= 0 && f.mat_eid[i] < M);
     for (int p = f.mat_ptr[i]; p < f.mat_ptr[i + 1]; p++) mat[i] += X[f.mat_ind[p]];
     CHECK(mat[i] == Xe[f.mat_eid[i]]);
+  }
+  // the same table through the streaming row gather's records (stream_rows_kernel): rows spread over the lane
+  // groups, chunks of long rows into partial rows, two fixup levels
+  const hg::RowStream &ms = f.mat_stream;
+  if (!ms.rec_tab.empty()) {
+    std::vector<int64_t> out((size_t)f.n_mat, INT64_MIN), part((size_t)ms.nslots, INT64_MIN);
+    for (const hg::SRec &rt : ms.rec_tab) {
+      CHECK(rt.off >= 0 && rt.off + rt.len <= (int64_t)ms.rec.size() && rt.len % 4 == 0 && rt.len <= ms.max_rec_words &&
+            rt.nslots >= 1 && rt.nslots <= ms.cap);
+      const int32_t *r = ms.rec.data() + rt.off;
+      CHECK(r[1] == rt.nslots && r[7] == rt.off_sidx && r[0] <= ms.max_steps);
+      const int32_t *gbase = r + r[4], *stream = r + r[5], *dstl = r + r[6], *sidx = r + r[7];
+      std::vector<int> seen((size_t)rt.nslots, 0);
+      for (int g = 0; g < ms.ng; g++) {
+        int slot = gbase[g];
+        int64_t sum = 0;
+        for (int st = 0; st < r[0]; st++) {
+          const uint32_t w = (uint32_t)stream[(size_t)st * ms.ng + g];
+          if ((int32_t)w == N) continue;  // idle, no flags
+          const uint32_t row = w & 0x3fffffffu;
+          CHECK(!(w & 0x40000000u) && (int)row <= N);
+          if ((int)row < N) sum += X[row];  // row N with the last flag: an empty row's single entry
+          if (w & 0x80000000u) {
+            CHECK(slot >= 0 && slot < rt.nslots && !seen[slot]);
+            seen[slot] = 1;
+            const int32_t d = dstl[slot];
+            if (d < 0) {
+              const int ps = d & 0x7fffffff;
+              CHECK(ps < ms.nslots && part[ps] == INT64_MIN && sidx[slot] == -1);
+              part[ps] = sum;
+            } else {
+              CHECK(d < f.n_mat && out[d] == INT64_MIN);
+              CHECK(sidx[slot] == (sum == 0 && f.mat_ptr[d + 1] == f.mat_ptr[d] ? -1 : f.mat_eid[d]));
+              out[d] = sum;
+            }
+            slot++;
+            sum = 0;
+          }
+        }
+        CHECK(sum == 0);
+      }
+      for (int k = 0; k < rt.nslots; k++) CHECK(seen[k]);
+    }
+    for (size_t i = 0; i < ms.fixups.size(); i++) {
+      const hg::Fixup &fx = ms.fixups[i];
+      CHECK(fx.first >= 0 && fx.count >= 1 && fx.first + fx.count <= ms.nslots && fx.row >= 0 && fx.row < f.n_mat);
+      int64_t sum = 0;
+      for (int k = 0; k < fx.count; k++) {
+        CHECK(part[fx.first + k] != INT64_MIN);
+        sum += part[fx.first + k];
+      }
+      if ((int)i < ms.n_fix_l1) {
+        CHECK(fx.pad >= 1 && fx.pad <= ms.nslots && part[fx.pad - 1] == INT64_MIN);
+        part[fx.pad - 1] = sum;
+      } else {
+        CHECK(fx.pad == 0 && out[fx.row] == INT64_MIN);
+        out[fx.row] = sum;
+      }
+    }
+    for (int i = 0; i < f.n_mat; i++) CHECK(out[i] == mat[i]);
+    g_stream_rows += f.n_mat;
+    g_stream_chunks += ms.nslots;
   }
   std::vector<int64_t> partial((size_t)f.n_part, INT64_MIN);
   std::vector<int64_t> tile;
@@ -340,7 +402,7 @@ int main(int argc, char **argv) {
   // the random graphs must actually have reached the hub pass, hub parts, split rows and two-level fixups
   std::printf("hub schedules %ld, hub rounds %ld, heavy hubs %ld, extra hub parts %ld, split vertices %ld, first-level fixups %ld\n",
               g_hub_graphs, g_hub_rounds, g_heavy, g_hub_parts, g_split_rows, g_l1_fixups);
-  CHECK(g_chunked > 200 && g_heavy > 50 && g_hub_graphs > 50 && g_hub_rounds > 10 * g_hub_graphs && g_hub_parts > 0 && g_split_rows > 100 && g_l1_fixups > 0);
+  CHECK(g_stream_rows > 10000 && g_stream_chunks > 100 && g_chunked > 200 && g_heavy > 50 && g_hub_graphs > 50 && g_hub_rounds > 10 * g_hub_graphs && g_hub_parts > 0 && g_split_rows > 100 && g_l1_fixups > 0);
   std::puts("sched_fuzz ok");
   return 0;
 }
