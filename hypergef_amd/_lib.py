@@ -56,7 +56,9 @@ class FusedInfo(ctypes.Structure):
                 ("n_split", ctypes.c_int32), ("fixups", ctypes.c_int32),
                 ("hub_rounds", ctypes.c_int32), ("hub_workgroups", ctypes.c_int32),
                 ("hub_entries", ctypes.c_int64), ("hub_pairs", ctypes.c_int64),
-                ("partial_rows", ctypes.c_int64)]
+                ("partial_rows", ctypes.c_int64),
+                ("record_words_max", ctypes.c_int32), ("stream_steps_max", ctypes.c_int32),
+                ("lds_bytes", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

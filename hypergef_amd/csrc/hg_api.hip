@@ -132,6 +132,18 @@ void fused_free(hg::FusedSched &f) {
 
 // Capacities of a fused panel for feature width F: `cap` hyperedge slots (rows of the
 // LDS tile, whole multiples of 16), four stream entries per slot on average.
+// The fused chain (panels, streaming row gather, fixups) moves rows as 16-byte lanes whatever their width and
+// base alignment when every table is addressable through a buffer descriptor (range-checked per dword, so
+// the lane holding a row's last columns may load past the row's end): class-count widths (F = 3, 6, 7, 67)
+// then run four floats per lane instead of one.  Mirrors `fast` in launch_fused_t.  Measured on the cora x1024
+// batch (profiles/r02_experiments.md): F = 9 0.120 -> 0.076 ms, 33 0.340 -> 0.277, 67 0.766 -> 0.498; rows of up
+// to 7 floats are faster one dword per lane (F = 7 0.072 vs 0.078, F = 3 0.047 vs 0.054) and stay there.
+bool wide_rows_ok(const hg_plan *p, int32_t F) {
+  return (F % 4 == 0 || F > 8) && p->N < (1 << 24) && p->M < (1 << 24) && F < (1 << 22) && (int64_t)p->N * F * 4 < ((int64_t)1 << 31) &&
+         (int64_t)p->M * F * 4 < ((int64_t)1 << 31);
+}
+bool plan_vec4(const hg_plan *p, int32_t F) { return F % 4 == 0 || wide_rows_ok(p, F); }
+
 void fused_caps(const hg_plan *p, int32_t F, bool vec4, int32_t &cap, int32_t &mem_cap, int32_t tile_bytes = 0) {
   const int row_bytes = hg::fused_tile_row_floats(F, vec4) * 4;
   const int c = std::max(16, std::min(256, (tile_bytes > 0 ? tile_bytes : p->opts.fused_tile_bytes) / row_bytes));
@@ -164,7 +176,7 @@ int get_fused(const hg_plan *cp, int32_t F, bool vec4, const hg::FusedSched **ou
   const int32_t ng = 256 / (row_floats / (vec4 ? 4 : 1));  // lane groups per workgroup
   // The hub pass reads X and the materialised table through buffer descriptors (row index below 2^24,
   // tables below 2 GiB) and exists for 16-byte lanes of at least 16 floats per row.
-  const bool allow_hub = vec4 && F >= 16 && p->N < (1 << 24) && (int64_t)p->N * F * 4 < ((int64_t)1 << 31) &&
+  const bool allow_hub = vec4 && F % 4 == 0 && F >= 16 && p->N < (1 << 24) && (int64_t)p->N * F * 4 < ((int64_t)1 << 31) &&
                          (int64_t)p->M * F * 4 < ((int64_t)1 << 31);
   const int64_t key = (((int64_t)cap * 1000000 + mem_cap) * 1000 + ng) * 2 + (allow_hub ? 1 : 0);
   std::lock_guard<std::mutex> lock(p->fused_mu);
@@ -266,7 +278,7 @@ FusedCarve fused_carve(const hg::FusedSched &f, int32_t F) {
   FusedCarve c;
   c.mat_part = round256((size_t)f.n_mat * F * sizeof(float));
   c.part = c.mat_part + round256((size_t)std::max(f.mat_sched.nslots, f.mat_stream.nslots) * F * sizeof(float));
-  c.total = c.part + round256((size_t)f.n_part * F * sizeof(float));
+  c.total = c.part + round256((size_t)f.n_part * F * sizeof(float) + 16);  // + 16: a lane may load past the last partial row's end
   return c;
 }
 // The pull layout always fits a pull call; a fused schedule that exists for this width (built by
@@ -659,7 +671,7 @@ int hg_plan_bind_scales(const hg_plan *cp, int32_t F, const float *degE, const f
     return HG_ERR_INVALID;
   }
   const hg::FusedSched *cf = nullptr;
-  int rc = get_fused(cp, F, F % 4 == 0, &cf);
+  int rc = get_fused(cp, F, plan_vec4(cp, F), &cf);
   if (rc != HG_OK) return rc;
   hg::FusedSched *f = const_cast<hg::FusedSched *>(cf);
   std::lock_guard<std::mutex> lock(const_cast<hg_plan *>(cp)->fused_mu);
@@ -706,7 +718,7 @@ int hg_plan_auto_variant(const hg_plan *p, int32_t F) {
   }
   int32_t variant = HG_VARIANT_PULL;
   const hg::FusedSched *f = nullptr;
-  int rc = pick_variant(p, F, F % 4 == 0, &variant, &f);
+  int rc = pick_variant(p, F, plan_vec4(p, F), &variant, &f);
   return rc != HG_OK ? rc : variant;
 }
 
@@ -716,7 +728,7 @@ int hg_plan_prepare(const hg_plan *p, int32_t F, hg_fused_info *info) {
     return HG_ERR_INVALID;
   }
   const hg::FusedSched *f = nullptr;
-  int rc = get_fused(p, F, F % 4 == 0, &f);
+  int rc = get_fused(p, F, plan_vec4(p, F), &f);
   if (rc != HG_OK) return rc;
   // the pull variant's schedules for this lane layout too: after hg_plan_prepare a call of any variant
   // allocates nothing
@@ -747,6 +759,10 @@ int hg_plan_prepare(const hg_plan *p, int32_t F, hg_fused_info *info) {
     info->hub_entries = f->hub.stream_entries;
     info->hub_pairs = f->hub.pairs;
     info->partial_rows = f->n_part;
+    info->record_words_max = f->max_rec_words;
+    info->stream_steps_max = f->max_steps;
+    info->lds_bytes = (int32_t)((size_t)f->cap * hg::fused_tile_row_floats(F, plan_vec4(p, F)) * 4 + (size_t)f->max_rec_words * 4 + 16);
+    info->reserved = 0;
   }
   return HG_OK;
 }
@@ -762,7 +778,7 @@ size_t hg_plan_workspace_bytes(const hg_plan *p, int32_t F) {
   // size for what HG_VARIANT_AUTO will run: resolving it builds the fused schedule if that is the choice
   int32_t variant = HG_VARIANT_PULL;
   const hg::FusedSched *f = nullptr;
-  (void)pick_variant(p, F, F % 4 == 0, &variant, &f);
+  (void)pick_variant(p, F, plan_vec4(p, F), &variant, &f);
   return workspace_need(p, F);
 }
 
@@ -883,7 +899,8 @@ static int aggr_impl(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
   const Carve c = carve(plan, F);
   char *ws = static_cast<char *>(workspace);
   float *Xe = reinterpret_cast<float *>(ws + c.xe);
-  const bool vec4 = (F % 4 == 0) && aligned16(X) && aligned16(Y) && aligned16(Xe);
+  const bool aligned = (F % 4 == 0) && aligned16(X) && aligned16(Y) && aligned16(Xe);
+  const bool vec4 = aligned || wide_rows_ok(plan, F);  // the fused chain's lane layout; the pull kernels decide for themselves
   const hg::FusedSched *f = nullptr;
   if (variant == HG_VARIANT_AUTO) {
     if ((rc = pick_variant(plan, F, vec4, &variant, &f)) != HG_OK) return rc;
@@ -987,7 +1004,7 @@ static int aggr_impl(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
     a.bsB = bound ? f->d_bsB : nullptr;
     a.bsD = bound ? f->d_bsD : nullptr;
     // rows produced outside the panels (hubs, split vertices) get no epilogue: two-step then
-    if (lin && f->fixups.empty() && vec4) {
+    if (lin && f->fixups.empty() && aligned) {
       a.Wlin = lin->Wlin;
       a.F_out = lin->F_out;
       a.epi = lin->epi;

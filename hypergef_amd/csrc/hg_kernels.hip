@@ -25,7 +25,9 @@ template <> struct Vec<1> {
   __device__ __forceinline__ static Vec load_buf(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return Vec{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0))};
   }
+  __device__ __forceinline__ static Vec loadu(const float *p) { return Vec{*p}; }
   __device__ __forceinline__ void store(float *p) const { *p = x; }
+  __device__ __forceinline__ void store_n(float *p, int) const { *p = x; }
   __device__ __forceinline__ void store_nt(float *p) const { __builtin_nontemporal_store(x, p); }
   __device__ __forceinline__ void add(const Vec &o) { x += o.x; }
   __device__ __forceinline__ void mul(float s) { x *= s; }
@@ -42,6 +44,24 @@ template <> struct Vec<4> {
     return Vec{__builtin_bit_cast(float4, (u4)__builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0))};
   }
   __device__ __forceinline__ void store(float *p) const { *reinterpret_cast<float4 *>(p) = v; }
+  // Rows whose width is not a multiple of four floats (or whose base is only 4-byte aligned) still move as
+  // 16-byte accesses: gfx950 takes dword-aligned dwordx4 loads and stores, the lane that holds a row's last
+  // columns stores only those (store_n), and what it loaded past the row's end stays in columns nobody reads.
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+  __device__ __forceinline__ static Vec loadu(const float *p) {
+    const f4u t = *reinterpret_cast<const f4u *>(p);
+    return Vec{make_float4(t.x, t.y, t.z, t.w)};
+  }
+  __device__ __forceinline__ void storeu(float *p) const { *reinterpret_cast<f4u *>(p) = f4u{v.x, v.y, v.z, v.w}; }
+  __device__ __forceinline__ void store_n(float *p, int n) const {  // n >= 1 columns of this lane exist
+    if (n >= 4) {
+      storeu(p);
+    } else {
+      p[0] = v.x;
+      if (n > 1) p[1] = v.y;
+      if (n > 2) p[2] = v.z;
+    }
+  }
   __device__ __forceinline__ void store_nt(float *p) const {
     typedef float f4 __attribute__((ext_vector_type(4)));
     __builtin_nontemporal_store(f4{v.x, v.y, v.z, v.w}, reinterpret_cast<f4 *>(p));
@@ -231,20 +251,20 @@ __global__ __launch_bounds__(256) void fixup_rows_kernel(const GatherArgs a, con
   for (; k + 4 <= fx.count; k += 4) {  // four slot loads in flight, added in slot order
     V v[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) v[j] = V::load(src + (int64_t)(k + j) * F);
+    for (int j = 0; j < 4; j++) v[j] = V::loadu(src + (int64_t)(k + j) * F);
 #pragma unroll
     for (int j = 0; j < 4; j++) acc.add(v[j]);
   }
-  for (; k < fx.count; k++) acc.add(V::load(src + (int64_t)k * F));
+  for (; k < fx.count; k++) acc.add(V::loadu(src + (int64_t)k * F));
   if (fx.pad > 0) {
-    acc.store(a.partial + (int64_t)(fx.pad - 1) * F + col);
+    acc.store_n(a.partial + (int64_t)(fx.pad - 1) * F + col, a.F - col);
     return;
   }
   const int srow = a.scale_map ? a.scale_map[fx.row] : fx.row;
   const int64_t drow = a.dst_map ? a.dst_map[fx.row] : fx.row;
   if (a.scaleA) acc.mul(a.scaleA[srow]);
   if (a.scaleB) acc.mul(a.scaleB[srow]);
-  acc.store(a.dst + drow * F + col);
+  acc.store_n(a.dst + drow * F + col, a.F - col);
 }
 
 // Diagnostic stamps: lane 0 of every wave adds the ticks since the previous stamp to a
@@ -834,7 +854,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LIN ? (LPR 
         const int pr = prow[r];  // vertex id, or bit 31 | partial row (a piece of a split vertex)
         float *dst = (pr < 0 ? a.partial + (int64_t)(pr & 0x7fffffff) * F : a.Y + (int64_t)pr * F) + col;
         if (DBG && (a.debug & 64)) acc.store_nt(dst);
-        else acc.store(dst);
+        else acc.store_n(dst, a.F - col);
       }
     }
   }
@@ -1120,7 +1140,7 @@ __global__ __launch_bounds__(256) void stream_rows_kernel(const StreamArgs a) {
         if (a.scaleB) acc.mul(sB[slot]);
         const int d = dstl[slot];
         slot++;
-        if (col_ok) acc.store((d < 0 ? a.partial + (int64_t)(d & 0x7fffffff) * F : a.dst + (int64_t)d * F) + col);
+        if (col_ok) acc.store_n((d < 0 ? a.partial + (int64_t)(d & 0x7fffffff) * F : a.dst + (int64_t)d * F) + col, a.F - col);
         acc = V::zero();
       }
     }
@@ -1294,7 +1314,7 @@ hipError_t launch_fixups(const Fixup *fixups, int nfix, int nfix_l1, int32_t F, 
   a.scaleA = scaleA;
   a.scaleB = scaleB;
   a.scale_map = scale_map;
-  const int lanes = vec4 ? F / 4 : F;
+  const int lanes = vec4 ? (F + 3) / 4 : F;  // vec4 here: 16-byte lanes over rows of any width (loadu / store_n)
   const int lpr = std::min(64, next_pow2(std::max(lanes, 1)));
 #define HG_CASE(L) \
   case L:          \
@@ -1450,6 +1470,7 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
       }
 #undef HG_PK
     }
+    if (a.F & 3) return hipErrorInvalidValue;  // other widths ride on the range-checked buffer loads only (hg_api: wide_rows_ok)
   }
   if (a.Wlin) return hipErrorInvalidValue;
   if constexpr (VEC == 1 && LPR >= 8) {  // F >= 5, not a multiple of 4 (class-count widths): the same buffer-load
@@ -1570,7 +1591,7 @@ hipError_t read_stamps(unsigned long long *out, bool reset) {
 // 32 row groups, 128 slots in a 16 KB tile -- instead of a few fat row groups and tiny panels.
 int fused_tile_row_floats(int F, bool vec4) {
   if (vec4 && tuning().fused_coltile && F > 32 && F % 32 == 0) return 32;
-  const int lanes = vec4 ? F / 4 : F;
+  const int lanes = vec4 ? (F + 3) / 4 : F;
   return std::min(64, next_pow2(std::max(lanes, 1))) * (vec4 ? 4 : 1);
 }
 

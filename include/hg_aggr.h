@@ -117,6 +117,10 @@ typedef struct hg_fused_info {
   int64_t hub_entries; /* row gathers of the hub pass */
   int64_t hub_pairs;   /* (hub, hyperedge) incidences served from the LDS tile */
   int64_t partial_rows; /* partial rows in the workspace (hub parts x workgroups + pieces) */
+  int32_t record_words_max; /* largest panel record, 32-bit words (staged in LDS beside the tile) */
+  int32_t stream_steps_max; /* longest entry stream of a panel: row gathers per lane group */
+  int32_t lds_bytes;        /* LDS per panel workgroup without scale staging: tile + largest record */
+  int32_t reserved;
 } hg_fused_info;
 
 HG_API int hg_version(void);

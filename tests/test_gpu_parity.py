@@ -1062,3 +1062,53 @@ def test_hub_pass_feature_widths(hg, oracle, F):
         yu = plan.aggregate(ptr, ind, Xd, _dev(degE.ravel()), _dev(degV.ravel()), _dev(W), variant="fused",
                             bind_scales=False).cpu().numpy()
         assert np.array_equal(yw, yu)
+
+
+@pytest.mark.parametrize("shape", ["cora", "citeseer", "powerlaw", "dense"])
+def test_rows_of_any_width_and_alignment(hg, oracle, shape):
+    """The fused chain moves rows as 16-byte lanes whatever their width (class-count widths: 3, 6, 7, 67) and
+    whatever the 4-byte alignment of X, Y and the workspace: dword-aligned dwordx4 accesses, the lane with a
+    row's last columns stores only those.  Every variant of the schedule takes part -- panels, sub-slots,
+    materialised rows through the streaming gather and its chunk fixups, pieces and their fixups -- weighted
+    and unweighted, against the oracle, with sentinel bands around Y and the workspace."""
+    from hypergef_amd.plan import Plan
+    inc = _make(shape)
+    ptr, ind = _dev(inc.csrptr), _dev(inc.colind)
+    plan = Plan.from_tensors(inc.N, ptr, ind)
+    H_ptr, H_ind = vertex_csr(inc, oracle)
+    degE, degV = oracle.degrees(inc.N, inc.M, inc.csrptr, inc.colind)
+    degE = np.where(np.isinf(degE), 0, degE).astype(np.float32)
+    rng = np.random.default_rng(11)
+    W = (rng.random(inc.M) + 0.5).astype(np.float32)
+    dE, dV, dW = _dev(degE), _dev(degV), _dev(W)
+    G = 1024
+    short = plan.info["max_len"][0] <= 8 and plan.info["max_len"][1] <= 16
+    for F, shift in ((1, 0), (3, 1), (5, 0), (6, 2), (7, 3), (9, 0), (33, 1), (67, 0), (130, 3), (257, 0), (301, 2),
+                     (32, 1), (64, 3), (8, 2)):
+        X = synth.features_like_reference(inc.N, F, seed=F)
+        ref_u = oracle.hyperaggr_host(inc.N, F, H_ptr, H_ind, inc.csrptr, inc.colind, X)
+        ref_w = oracle.hgnn_check(inc.N, inc.M, F, H_ptr, H_ind, inc.csrptr, inc.colind, X, degE, degV, W)
+        xbuf = torch.zeros(shift + inc.N * F, device=DEV)
+        Xd = xbuf[shift:shift + inc.N * F].view(inc.N, F)
+        Xd.copy_(_dev(X))
+        plan.prepare(F)  # the forced fused variant's schedule exists before the workspace is sized
+        nws = (plan.workspace_bytes(F) + 3) // 4
+        for weighted in (False, True):
+            ybuf = torch.full((G + shift + inc.N * F + G,), 7.25, device=DEV)
+            wbuf = torch.full((G + nws + G,), 7.25, device=DEV)  # the workspace itself must be 256-byte aligned
+            Y = ybuf[G + shift:G + shift + inc.N * F].view(inc.N, F)
+            ws = wbuf[G:G + nws].view(torch.uint8)
+            if weighted:
+                plan.aggregate(ptr, ind, Xd, dE, dV, dW, variant="fused", out=Y, workspace=ws)
+            else:
+                plan.aggregate(ptr, ind, Xd, variant="fused", out=Y, workspace=ws)
+            torch.cuda.synchronize()
+            for buf, n, sh in ((ybuf, inc.N * F, shift), (wbuf, nws, 0)):
+                assert bool((buf[:G + sh] == 7.25).all()) and bool((buf[G + sh + n:] == 7.25).all()), (shape, F, shift)
+            y = Y.cpu().numpy()
+            if short:  # the CPU order, bit for bit
+                assert np.array_equal(y, ref_w if weighted else ref_u), (shape, F, shift, weighted)
+            else:  # rows of 10^4 terms: the float64 answer (the fp32 oracle's one long chain is the less accurate side)
+                truth = _float64_truth(inc, X, degE, degV, W) if weighted else _float64_truth(inc, X)
+                assert (np.abs(y - truth) <= 1e-5 * np.maximum(1.0, np.abs(truth))).all(), (shape, F, shift, weighted)
+                np.testing.assert_allclose(y, ref_w if weighted else ref_u, rtol=2e-4, atol=1e-5)

@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 from hypergef_amd import plan as planmod, synth, _lib
 dev = "cuda:0"
-K, F = 1024, 32
+K, F = int(os.environ.get("STAMP_K", "1024")), int(os.environ.get("STAMP_F", "32"))
 inc = synth.replicate_block_diagonal(synth.cora_shape(), K)
 ptr, ind = torch.from_numpy(inc.csrptr).to(dev), torch.from_numpy(inc.colind).to(dev)
 X = torch.rand(inc.N, F, device=dev)
@@ -34,4 +34,4 @@ waves = info["panels"] * 4 * n
 clk = 1e8  # s_memtime ticks at 100 MHz on this part
 for i, nm in enumerate(names):
     print("%-28s %6.1f %%   %8.3f us/wave" % (nm, 100.0 * buf[i] / tot, buf[i] / waves / clk * 1e6))
-print("total us/wave %.3f" % (tot / waves / clk * 1e6))
+print("F=%d panels %d cap %d: total us/wave %.3f" % (F, info["panels"], info["cap"], tot / waves / clk * 1e6))
