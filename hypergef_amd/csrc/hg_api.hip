@@ -266,7 +266,7 @@ Carve carve(const hg_plan *p, int32_t F) {
   size_t off = round256((size_t)p->M * F * sizeof(float));
   for (int h = 0; h < 2; h++) {
     c.part[h] = off;
-    off += round256((size_t)std::max(p->sched[h].nslots, p->stream_nslots[h]) * F * sizeof(float));
+    off += round256((size_t)std::max(p->sched[h].nslots, p->stream_nslots[h]) * F * sizeof(float) + 16);  // + 16: see fused_carve
   }
   c.total = off;
   return c;
@@ -420,9 +420,11 @@ int get_row_stream(const hg_plan *cp, int hop, int32_t ng, const hg::RowStream *
 int run_hop(const hg_plan *p, int hop, int32_t F, const int32_t *ptr, const int32_t *ind,
             const float *src, const float *scaleA, const float *scaleB, float *dst,
             float *partial, hipStream_t stream) {
-  const bool vec4 = (F % 4 == 0) && aligned16(src) && aligned16(dst) && aligned16(partial);
+  // 16-byte lanes over rows of any width above 8 floats and any 4-byte alignment (wide_rows_ok): the stream
+  // kernel loads through a range-checked descriptor and stores only the columns that exist
+  const bool lanes16 = F % 4 == 0 || F > 8;
   const int64_t nsrc = hop == 0 ? p->N : p->M, sb = nsrc * F * 4;
-  if (vec4 && nsrc < (1 << 24) && sb > 0 && sb < ((int64_t)1 << 31) && !(p->opts.flags & HG_PLAN_NO_ROW_STREAM)) {
+  if (lanes16 && F < (1 << 22) && nsrc < (1 << 24) && sb > 0 && sb < ((int64_t)1 << 31) && !(p->opts.flags & HG_PLAN_NO_ROW_STREAM)) {
     const int32_t ng = 256 / (hg::fused_tile_row_floats(F, true) / 4);
     const hg::RowStream *rs = nullptr;
     int rc = get_row_stream(p, hop, ng, &rs);
@@ -732,7 +734,7 @@ int hg_plan_prepare(const hg_plan *p, int32_t F, hg_fused_info *info) {
   if (rc != HG_OK) return rc;
   // the pull variant's schedules for this lane layout too: after hg_plan_prepare a call of any variant
   // allocates nothing
-  if (!(p->opts.flags & (HG_PLAN_HOST_ONLY | HG_PLAN_NO_ROW_STREAM)) && F % 4 == 0) {
+  if (!(p->opts.flags & (HG_PLAN_HOST_ONLY | HG_PLAN_NO_ROW_STREAM)) && (F % 4 == 0 || F > 8)) {
     const int32_t ng = 256 / (hg::fused_tile_row_floats(F, true) / 4);
     for (int hop = 0; hop < 2; hop++) {
       const int64_t nsrc = hop == 0 ? p->N : p->M;

@@ -1098,17 +1098,19 @@ def test_rows_of_any_width_and_alignment(hg, oracle, shape):
             wbuf = torch.full((G + nws + G,), 7.25, device=DEV)  # the workspace itself must be 256-byte aligned
             Y = ybuf[G + shift:G + shift + inc.N * F].view(inc.N, F)
             ws = wbuf[G:G + nws].view(torch.uint8)
-            if weighted:
-                plan.aggregate(ptr, ind, Xd, dE, dV, dW, variant="fused", out=Y, workspace=ws)
-            else:
-                plan.aggregate(ptr, ind, Xd, variant="fused", out=Y, workspace=ws)
-            torch.cuda.synchronize()
-            for buf, n, sh in ((ybuf, inc.N * F, shift), (wbuf, nws, 0)):
-                assert bool((buf[:G + sh] == 7.25).all()) and bool((buf[G + sh + n:] == 7.25).all()), (shape, F, shift)
-            y = Y.cpu().numpy()
-            if short:  # the CPU order, bit for bit
-                assert np.array_equal(y, ref_w if weighted else ref_u), (shape, F, shift, weighted)
-            else:  # rows of 10^4 terms: the float64 answer (the fp32 oracle's one long chain is the less accurate side)
-                truth = _float64_truth(inc, X, degE, degV, W) if weighted else _float64_truth(inc, X)
-                assert (np.abs(y - truth) <= 1e-5 * np.maximum(1.0, np.abs(truth))).all(), (shape, F, shift, weighted)
-                np.testing.assert_allclose(y, ref_w if weighted else ref_u, rtol=2e-4, atol=1e-5)
+            for variant in ("fused", "pull"):  # pull: the streaming row gather takes the same widths
+                Y.fill_(7.25)
+                if weighted:
+                    plan.aggregate(ptr, ind, Xd, dE, dV, dW, variant=variant, out=Y, workspace=ws)
+                else:
+                    plan.aggregate(ptr, ind, Xd, variant=variant, out=Y, workspace=ws)
+                torch.cuda.synchronize()
+                for buf, n, sh in ((ybuf, inc.N * F, shift), (wbuf, nws, 0)):
+                    assert bool((buf[:G + sh] == 7.25).all()) and bool((buf[G + sh + n:] == 7.25).all()), (shape, F, shift, variant)
+                y = Y.cpu().numpy()
+                if short:  # the CPU order, bit for bit
+                    assert np.array_equal(y, ref_w if weighted else ref_u), (shape, F, shift, weighted, variant)
+                else:  # rows of 10^4 terms: the float64 answer (the fp32 oracle's one long chain is the less accurate side)
+                    truth = _float64_truth(inc, X, degE, degV, W) if weighted else _float64_truth(inc, X)
+                    assert (np.abs(y - truth) <= 1e-5 * np.maximum(1.0, np.abs(truth))).all(), (shape, F, shift, weighted, variant)
+                    np.testing.assert_allclose(y, ref_w if weighted else ref_u, rtol=2e-4, atol=1e-5)
