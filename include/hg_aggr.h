@@ -225,6 +225,8 @@ HG_API size_t hg_plan_workspace_bytes(const hg_plan *plan, int32_t F);
  *   Arithmetic order is the reference test's (test/hgnn_test.py:56-63):
  *     Xe = ((sum X) * degE) * W ;  Y = (sum Xe) * degV.
  *   Y is fully overwritten (no pre-zeroing needed); inputs are not modified.
+ *   X, Y: row-major [N, F], any F >= 1, 4-byte aligned (16-byte alignment and F % 4 == 0 are not required:
+ *   rows of more than 8 floats move as 16-byte lanes either way).
  *   workspace: device scratch of at least hg_plan_workspace_bytes(plan, F),
  *   256-byte aligned, private to this call until it completes on `stream`.
  *   csrptr_t / colind_t must be the arrays the plan was built from. */
