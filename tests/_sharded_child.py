@@ -17,7 +17,7 @@ def main():
     dist.init_process_group("gloo")  # before anything touches the GPU
     rank, world = dist.get_rank(), dist.get_world_size()
     from hypergef_amd import synth
-    from hypergef_amd.dist import ShardedAggregator
+    from hypergef_amd.dist import ColumnShardedAggregator, ShardedAggregator
     from oracle import oracle as orc
     orc.build()
     dev = torch.device("cuda", 0)
@@ -45,6 +45,16 @@ def main():
     rows = rs.aggregate(Xd, dE, dV, Wd)
     lo, hi = rs.row_range()
     assert rows.shape == (hi - lo, F) and tol(rows.cpu().numpy(), ref[lo:hi]).all()
+
+    # column slices pipelined against their collectives (SURVEY 8(e) iv), and column sharding (v): HIP operator
+    piped = ShardedAggregator(inc, device=dev, column_chunks=4).aggregate(Xd, dE, dV, Wd)
+    assert tol(piped.cpu().numpy(), ref).all()
+    rows_p = ShardedAggregator(inc, device=dev, exchange="reduce_scatter", column_chunks=2).aggregate(Xd, dE, dV, Wd)
+    assert rows_p.shape == (hi - lo, F) and tol(rows_p.cpu().numpy(), ref[lo:hi]).all()
+    cols = ColumnShardedAggregator(inc, device=dev)
+    c0, c1 = cols.columns(F)
+    assert tol(cols.aggregate(Xd, dE, dV, Wd).cpu().numpy(), ref[:, c0:c1]).all()
+    assert tol(cols.aggregate(Xd, dE, dV, Wd, gather=True).cpu().numpy(), ref).all()
 
     # autograd through the sharded operator: the reference's backward rule (forward on grad_out,
     # hgnnaggr.cc:51-64) applied shard by shard, partial gradients summed by the same collective

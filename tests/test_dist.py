@@ -14,7 +14,8 @@ import torch.multiprocessing as mp
 
 from conftest import ROOT
 from hypergef_amd import synth
-from hypergef_amd.dist import ShardedAggregator, local_incidence, partition_hyperedges, shared_vertices
+from hypergef_amd.dist import (ColumnShardedAggregator, ShardedAggregator, local_incidence, partition_hyperedges,
+                               shared_vertices)
 
 
 def _free_port():
@@ -58,7 +59,7 @@ def _worker(rank, world, port, out_dir):
 
     def local_op(loc, Xt, dE, dV, Wt):
         Hp, Hi = orc.transpose_csr(loc.M, loc.N, loc.csrptr, loc.colind)
-        y = orc.hgnn_check(loc.N, loc.M, F, Hp, Hi, loc.csrptr, loc.colind, Xt.numpy(),
+        y = orc.hgnn_check(loc.N, loc.M, Xt.shape[1], Hp, Hi, loc.csrptr, loc.colind, Xt.numpy(),
                            None if dE is None else dE.numpy(), None if dV is None else dV.numpy(),
                            None if Wt is None else Wt.numpy())
         return torch.from_numpy(y)
@@ -85,6 +86,24 @@ def _worker(rank, world, port, out_dir):
     lo, hi = rs.row_range()
     assert rows.shape == (hi - lo, F) and rs.row_range(world - 1)[1] == inc.N and rs.row_range(0)[0] == 0
     np.testing.assert_allclose(rows.numpy(), ref[lo:hi], rtol=1e-5, atol=1e-6)
+    # column_chunks: the same sums, the collective of one column slice overlapping the next slice's aggregation
+    args = (torch.from_numpy(X), torch.from_numpy(degE), torch.from_numpy(degV), torch.from_numpy(W))
+    for chunks in (2, 3, 8):
+        piped = ShardedAggregator(inc, local_op=local_op, column_chunks=chunks)
+        assert [c1 - c0 for c0, c1 in piped.column_slices(F)] == {2: [3, 3], 3: [2, 2, 2], 8: [1] * 6}[chunks]
+        assert torch.equal(piped.aggregate(*args), Y)
+        rows_p = ShardedAggregator(inc, local_op=local_op, exchange="reduce_scatter", column_chunks=chunks).aggregate(*args)
+        assert torch.equal(rows_p, rows)
+    assert ShardedAggregator(inc, local_op=local_op, column_chunks=4).column_slices(64) == [(0, 16), (16, 32), (32, 48), (48, 64)]
+    # column sharding: the whole hypergraph on every rank, F / world columns each, no collective
+    cols = ColumnShardedAggregator(inc, local_op=local_op)
+    c0, c1 = cols.columns(F)
+    assert cols.columns(F, 0)[0] == 0 and cols.columns(F, world - 1)[1] == F
+    np.testing.assert_allclose(cols.aggregate(*args).numpy(), ref[:, c0:c1], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(cols.aggregate(*args, gather=True).numpy(), ref, rtol=1e-5, atol=1e-6)
+    X5 = torch.from_numpy(np.ascontiguousarray(X[:, :5]))  # a width the ranks cannot split evenly
+    ref5 = orc.hgnn_check(inc.N, inc.M, 5, Hp, Hi, inc.csrptr, inc.colind, X[:, :5].copy(), degE, degV, W)
+    np.testing.assert_allclose(cols.aggregate(X5, *args[1:], gather=True).numpy(), ref5, rtol=1e-5, atol=1e-6)
     open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
     dist.destroy_process_group()
 
