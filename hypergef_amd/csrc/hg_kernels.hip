@@ -636,6 +636,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *partial,
 // row, bit 30 = row of the materialised table, bit 31 = last member of its slot
 // (scale, store to the LDS tile, start the next slot).  Members of a slot stay in
 // their CSR order, so the arithmetic is still the CPU reference's.
+// Waves per SIMD the LIN instances (panel kernel + matrix phase) are compiled for, by lanes per row: the register
+// budget that follows (512 / waves) decides how much of hop 2's row registers and the B fragments spill.  Measured
+// (tools/linear_probe.py, cora x1024): F = 32 -> 32: 8 waves 0.262 ms, 7 0.258, 6 0.236, 5 0.249; 64 -> 64: 8 waves
+// 0.621, 7 0.539, 6 0.507, 5 0.529, 4 0.532; 128 -> 128 (x256): 6 waves 0.739 (spills), 5 0.370, 4 0.388.
+#ifndef HG_LIN_WAVES8
+#define HG_LIN_WAVES8 6
+#endif
+#ifndef HG_LIN_WAVES16
+#define HG_LIN_WAVES16 6
+#endif
+#ifndef HG_LIN_WAVES32
+#define HG_LIN_WAVES32 5
+#endif
 typedef unsigned hg_u4 __attribute__((ext_vector_type(4)));
 typedef int hg_i4 __attribute__((ext_vector_type(4)));
 
@@ -650,7 +663,7 @@ typedef int hg_i4 __attribute__((ext_vector_type(4)));
 // LIN: the rows a panel produces go through panel_times_wt (Y = rows * Wlin^T, F_out columns)
 // instead of straight to Y; needs F == LPR * VEC and at most 4 rows per lane group.
 template <int LPR, int VEC, int U, bool FAST, bool MAT, bool SCALED, bool DBG, bool LIN = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LIN ? (LPR >= 32 ? 5 : 8) : 1, 8))) void fused_packed_kernel(const FusedArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LIN ? (LPR >= 32 ? HG_LIN_WAVES32 : LPR == 16 ? HG_LIN_WAVES16 : HG_LIN_WAVES8) : 1, 8))) void fused_packed_kernel(const FusedArgs a) {
   constexpr int BS = 256;
   constexpr int NG = BS / LPR;
   constexpr int TW = LPR * VEC;
