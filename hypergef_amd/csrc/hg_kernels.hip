@@ -17,6 +17,11 @@
 
 namespace hg {
 
+// Waves per SIMD linear_rows_kernel is compiled for at K <= 64 (tools/linear_probe.py, 2.77 M rows): 64 x 64: 8 waves
+// 0.550 ms (spills; rocBLAS 0.427), 7 0.315, 6 0.311; 32 x 32: 8 waves 0.147, 7 0.141, 6 0.149.
+#ifndef HG_ROWS_WAVES
+#define HG_ROWS_WAVES 7
+#endif
 template <int VEC> struct Vec;
 template <> struct Vec<1> {
   float x;
@@ -499,7 +504,7 @@ template <int KSTEPS> struct LinearRows {
   static constexpr int R = KSTEPS >= 32 ? 32 : 64;
 };
 template <int KSTEPS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KSTEPS >= 32 ? 5 : 8, 8))) void linear_rows_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KSTEPS >= 32 ? 5 : HG_ROWS_WAVES, 8))) void linear_rows_kernel(
     const LinearArgs a) {
   constexpr int K = KSTEPS * 4, LD = K + 4, R = LinearRows<KSTEPS>::R;
   __shared__ float t[R * LD];
