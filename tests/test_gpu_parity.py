@@ -1114,3 +1114,33 @@ def test_rows_of_any_width_and_alignment(hg, oracle, shape):
                     truth = _float64_truth(inc, X, degE, degV, W) if weighted else _float64_truth(inc, X)
                     assert (np.abs(y - truth) <= 1e-5 * np.maximum(1.0, np.abs(truth))).all(), (shape, F, shift, weighted, variant)
                     np.testing.assert_allclose(y, ref_w if weighted else ref_u, rtol=2e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("K,F", [(406, 512), (1551, 512)])
+def test_tables_beyond_2GiB_use_64bit_offsets(hg, oracle, K, F):
+    """X and Y of 2.25 GB (byte offsets beyond 2^31: no buffer descriptor, the kernels fall back to 64-bit
+    pointer arithmetic) and of 8.6 GB (N*F beyond 2^31 ELEMENTS: where the reference's `int` index math
+    `v*F+k` overflows, hgnnaggr_cuda.cu:34).  The batch is block-diagonal, so every hypergraph of
+    it can be checked on its own: first, middle and last against the oracle on one cora-shape graph, bit for
+    bit (their hyperedges are short: the CPU order is kept), fused and pull."""
+    from hypergef_amd.plan import Plan
+    one = synth.cora_shape()
+    inc = synth.replicate_block_diagonal(one, K)
+    assert inc.N * F * 4 >= 2 ** 31 and (K < 1000 or inc.N * F >= 2 ** 31)
+    ptr, ind = _dev(inc.csrptr), _dev(inc.colind)
+    plan = Plan.from_tensors(inc.N, ptr, ind)
+    H_ptr, H_ind = vertex_csr(one, oracle)
+    torch.manual_seed(K)
+    X = torch.rand(inc.N, F, device=DEV)
+    plan.prepare(F)
+    ws = torch.empty(plan.workspace_bytes(F), dtype=torch.uint8, device=DEV)
+    Y = torch.empty(inc.N, F, device=DEV)
+    for variant in ("fused", "pull"):
+        Y.fill_(-1.0)
+        plan.aggregate(ptr, ind, X, variant=variant, out=Y, workspace=ws)
+        for r in (0, K // 2, K - 1):
+            rows = slice(r * one.N, (r + 1) * one.N)
+            ref = oracle.hyperaggr_host(one.N, F, H_ptr, H_ind, one.csrptr, one.colind, X[rows].cpu().numpy())
+            assert np.array_equal(Y[rows].cpu().numpy(), ref), (variant, r)
+    del X, Y, ws
+    torch.cuda.empty_cache()
