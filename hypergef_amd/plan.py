@@ -211,16 +211,19 @@ class Plan:
         exactly 1.0f is the identity, so such a W is not passed on at all -- same bits, no multiply, and the
         layers of a model then share ONE bound scale set instead of re-binding at every call.  Checked once
         per tensor (address, torch version counter); `bind_scales=False` skips the shortcut as it skips binding."""
-        if W is None or not enable:
+        if W is None or not enable or W.requires_grad:
             return W
         if not hasattr(self, "_unit_w"):
-            self._unit_w = {}
+            self._unit_w, self._unit_w_misses = {}, 0
         key = (W.data_ptr(), W._version, W.numel())
         hit = self._unit_w.get(key)
         if hit is None:
+            if self._unit_w_misses >= 16:  # weights that keep changing and are never all ones: stop looking
+                return W                   # (the check reads one flag back from the device)
             if len(self._unit_w) > 64:
                 self._unit_w.clear()
             hit = self._unit_w[key] = (bool((W == 1).all().item()), W)  # keeps W (and its address) alive
+            self._unit_w_misses = 0 if hit[0] else self._unit_w_misses + 1
         return None if hit[0] else W
 
     def _bind_scales(self, F, degE, degV, W, device, enable=True):
