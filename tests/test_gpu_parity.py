@@ -1144,3 +1144,63 @@ def test_tables_beyond_2GiB_use_64bit_offsets(hg, oracle, K, F):
             assert np.array_equal(Y[rows].cpu().numpy(), ref), (variant, r)
     del X, Y, ws
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_graphs_widths_and_options_differential(hg, oracle, seed):
+    """Differential sweep: per seed a random hypergraph family (uniform, heavy-tailed with hub vertices, a
+    few giant hyperedges, many empty hyperedges / isolated vertices, a small block-diagonal batch), random
+    feature widths (1 .. 300, aligned or not), random plan options (tile size, t_big, hub pass and row
+    stream on / off) and every variant, weighted and unweighted, against the float64 answer at 1e-5 of the
+    row's l1 mass (the bound that holds for any summation order) and against the oracle."""
+    from hypergef_amd.plan import Plan, make_opts
+    rng = np.random.default_rng(1000 + seed)
+    kind = seed % 6
+    if kind == 0:
+        inc = synth.random_incidence(int(rng.integers(50, 4000)), int(rng.integers(20, 3000)), float(rng.uniform(1.5, 12)),
+                                     seed=seed, empty_frac=float(rng.uniform(0, 0.3)))
+    elif kind == 1:
+        inc = synth.powerlaw(int(rng.integers(2000, 30000)), int(rng.integers(4000, 80000)), seed=seed,
+                             max_size=int(rng.integers(64, 4096)))
+    elif kind == 2:  # a few hyperedges containing most vertices
+        inc = synth.random_incidence(3000, 60, 900.0, seed=seed)
+    elif kind == 3:
+        inc = synth.replicate_block_diagonal(synth.citeseer_shape(seed=seed), int(rng.integers(2, 9)))
+    elif kind == 4:
+        inc = synth.random_incidence(int(rng.integers(5000, 20000)), int(rng.integers(100, 800)), float(rng.uniform(20, 200)),
+                                     seed=seed, empty_frac=0.5)
+    else:
+        inc = synth.powerlaw(60_000, 200_000, seed=seed)  # a vertex in tens of thousands of hyperedges
+    H_ptr, H_ind = vertex_csr(inc, oracle)
+    degE, degV = oracle.degrees(inc.N, inc.M, inc.csrptr, inc.colind)
+    degE = np.where(np.isinf(degE), 0, degE).astype(np.float32)
+    W = (rng.random(inc.M) + 0.5).astype(np.float32)
+    ptr, ind = _dev(inc.csrptr), _dev(inc.colind)
+    dE, dV, dW = _dev(degE), _dev(degV), _dev(W)
+    widths = [int(rng.integers(1, 17)), int(rng.integers(17, 130)), int(rng.choice([16, 32, 64, 128, 256])), int(rng.integers(130, 301))]
+    for F in widths:
+        opts = make_opts(fused_tile_bytes=int(rng.choice([0, 0, 4096, 32768])), t_big=int(rng.choice([0, 0, 2, 32])),
+                         hub_pass=bool(rng.integers(0, 2)), row_stream=bool(rng.integers(0, 2)))
+        plan = Plan.from_tensors(inc.N, ptr, ind, opts)
+        try:
+            plan.prepare(F)
+        except hg._lib.HgError as exc:  # an option set the LDS cannot hold is rejected up front, not at launch
+            assert "LDS" in str(exc)
+            continue
+        X = rng.standard_normal((inc.N, F)).astype(np.float32)
+        shift = int(rng.integers(0, 4))
+        xbuf = torch.zeros(shift + inc.N * F, device=DEV)
+        Xd = xbuf[shift:].view(inc.N, F)
+        Xd.copy_(_dev(X))
+        for weighted in (False, True):
+            truth = _float64_truth(inc, X, degE, degV, W) if weighted else _float64_truth(inc, X)
+            mass = _float64_truth(inc, np.abs(X), degE, degV, W) if weighted else _float64_truth(inc, np.abs(X))
+            ref = (oracle.hgnn_check(inc.N, inc.M, F, H_ptr, H_ind, inc.csrptr, inc.colind, X, degE, degV, W) if weighted
+                   else oracle.hyperaggr_host(inc.N, F, H_ptr, H_ind, inc.csrptr, inc.colind, X))
+            for variant in ("auto", "fused", "pull"):
+                args = (dE, dV, dW) if weighted else ()
+                y = plan.aggregate(ptr, ind, Xd, *args, variant=variant).cpu().numpy()
+                assert np.isfinite(y).all(), (seed, F, variant, weighted)
+                bad = np.abs(y - truth) > 1e-5 * np.maximum(1.0, mass)
+                assert not bad.any(), (seed, inc.name, F, shift, variant, weighted, int(bad.sum()), np.argwhere(bad)[:3])
+                np.testing.assert_allclose(y, ref, rtol=2e-3, atol=1e-5 * float(np.abs(mass).max()))
