@@ -323,6 +323,22 @@ def single_graph_latency(state, F, dev, sync, shape):
         g.replay()
         _, d = timed_steps(g.replay, 20, sync, lambda: None)
         single[var + "_us"] = d / 400 * 1e6
+    # what "auto" runs after the timed choice (hg_plan_tune_f32, the counterpart of the reference's tuner)
+    tuned = pl1.tune(p1, i1, X1)
+
+    def fa():
+        pl1.aggregate(p1, i1, X1, out=Y1, workspace=ws1, variant="auto")
+    for _ in range(20):
+        fa()
+    g = torch.cuda.CUDAGraph()
+    sync()
+    with torch.cuda.graph(g):
+        for _ in range(20):
+            fa()
+    g.replay()
+    _, d = timed_steps(g.replay, 20, sync, lambda: None)
+    single["auto_tuned_us"] = d / 400 * 1e6
+    single["tuned_choice"] = tuned["variant"] + ("" if tuned["variant"] == "fused" else "/hop kernels %d" % tuned["pull_hop_kernels"])
     single["reference_rtx3090_us"] = {"cora": 4.79, "citeseer": 3.70, "pubmed": 12.48}.get(shape)
     single["note"] = "device time per aggregation, 20 back-to-back aggregations per hipGraph replay"
     return single

@@ -28,7 +28,7 @@ VARIANTS = {"auto": HG_VARIANT_AUTO, "pull": HG_VARIANT_PULL, "push_atomic": HG_
 SYMBOLS = (
     "hg_version", "hg_last_error", "hg_status_string", "hg_balance_schedule", "hg_mtx_read", "hg_free",
     "hg_plan_create_host", "hg_plan_create_device", "hg_plan_destroy", "hg_plan_get_info",
-    "hg_plan_get_vertex_csr", "hg_plan_get_vertex_csr_device", "hg_plan_get_schedule", "hg_plan_prepare", "hg_plan_auto_variant", "hg_plan_bind_scales",
+    "hg_plan_get_vertex_csr", "hg_plan_get_vertex_csr_device", "hg_plan_get_schedule", "hg_plan_prepare", "hg_plan_auto_variant", "hg_plan_bind_scales", "hg_plan_tune_f32",
     "hg_plan_workspace_bytes",
     "hg_aggr_fused_f32", "hg_linear_pack_f32", "hg_linear_rows_f32", "hg_linear_wgrad_workspace_bytes", "hg_linear_wgrad_f32", "hg_aggr_linear_workspace_bytes", "hg_aggr_linear_f32", "hg_aggr_linear_res_f32",
     "hg_gather_rows_f32", "hg_aggr_push_groups_f32", "hg_gather_max_f32",
@@ -47,6 +47,11 @@ class PlanOpts(ctypes.Structure):
                 ("panel_rows", ctypes.c_int32), ("panel_nnz", ctypes.c_int32),
                 ("flags", ctypes.c_int32), ("t_big", ctypes.c_int32),
                 ("fused_tile_bytes", ctypes.c_int32), ("fused_steps", ctypes.c_int32)]
+
+
+class TuneInfo(ctypes.Structure):
+    _fields_ = [("variant", ctypes.c_int32), ("pull_hop_kernels", ctypes.c_int32), ("us", ctypes.c_float * 5),
+                ("reserved", ctypes.c_int32)]
 
 
 class FusedInfo(ctypes.Structure):
@@ -125,6 +130,8 @@ def lib():
     L.hg_plan_get_schedule.argtypes = [vp, i32, vp, vp, vp]
     L.hg_plan_prepare.restype = ctypes.c_int
     L.hg_plan_prepare.argtypes = [vp, i32, ctypes.POINTER(FusedInfo)]
+    L.hg_plan_tune_f32.restype = ctypes.c_int
+    L.hg_plan_tune_f32.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, sz, i32, vp, ctypes.POINTER(TuneInfo)]
     L.hg_linear_pack_f32.restype = ctypes.c_int
     L.hg_linear_pack_f32.argtypes = [i32, i32, vp, vp, vp]
     L.hg_linear_wgrad_workspace_bytes.restype = sz

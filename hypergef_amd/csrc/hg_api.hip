@@ -424,7 +424,14 @@ int run_hop(const hg_plan *p, int hop, int32_t F, const int32_t *ptr, const int3
   // kernel loads through a range-checked descriptor and stores only the columns that exist
   const bool lanes16 = F % 4 == 0 || F > 8;
   const int64_t nsrc = hop == 0 ? p->N : p->M, sb = nsrc * F * 4;
-  if (lanes16 && F < (1 << 22) && nsrc < (1 << 24) && sb > 0 && sb < ((int64_t)1 << 31) && !(p->opts.flags & HG_PLAN_NO_ROW_STREAM)) {
+  bool tuned_off = false;  // hg_plan_tune_f32 found the panel / task kernel faster for this hop and width
+  {
+    hg_plan *mp = const_cast<hg_plan *>(p);
+    std::lock_guard<std::mutex> lock(mp->auto_mu);
+    auto it = mp->hop_kernel.find(F);
+    tuned_off = it != mp->hop_kernel.end() && ((it->second >> hop) & 1);
+  }
+  if (!tuned_off && lanes16 && F < (1 << 22) && nsrc < (1 << 24) && sb > 0 && sb < ((int64_t)1 << 31) && !(p->opts.flags & HG_PLAN_NO_ROW_STREAM)) {
     const int32_t ng = 256 / (hg::fused_tile_row_floats(F, true) / 4);
     const hg::RowStream *rs = nullptr;
     int rc = get_row_stream(p, hop, ng, &rs);
@@ -1041,6 +1048,85 @@ int hg_aggr_fused_f32(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
                       size_t workspace_bytes, int32_t variant, hg_stream_t stream) {
   return aggr_impl(plan, F, csrptr_t, colind_t, X, degE, degV, W, Y, workspace, workspace_bytes, variant,
                    stream, nullptr);
+}
+
+int hg_plan_tune_f32(const hg_plan *plan, int32_t F, const int32_t *csrptr_t, const int32_t *colind_t,
+                     const float *X, const float *degE, const float *degV, const float *W, float *Y,
+                     void *workspace, size_t workspace_bytes, int32_t iters, hg_stream_t stream,
+                     hg_tune_info *info) {
+  int rc = check_call(plan, F, workspace, workspace_bytes);
+  if (rc != HG_OK) return rc;
+  if (iters <= 0) iters = 20;
+  hg_plan *mp = const_cast<hg_plan *>(plan);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const char *ws = static_cast<const char *>(workspace);
+  const bool aligned = (F % 4 == 0) && aligned16(X) && aligned16(Y) && aligned16(ws);
+  const int64_t key = (int64_t)F * 2 + ((aligned || wide_rows_ok(plan, F)) ? 1 : 0);
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+    hg::set_error("hg_plan_tune_f32: hipEventCreate failed");
+    return HG_ERR_HIP;
+  }
+  float us[5] = {-1.f, -1.f, -1.f, -1.f, -1.f};
+  auto set_choice = [&](int32_t variant, int32_t mask) {
+    std::lock_guard<std::mutex> lock(mp->auto_mu);
+    mp->auto_choice[key] = variant;
+    mp->hop_kernel[F] = mask;
+  };
+  rc = HG_OK;
+  for (int c = 0; c < 5 && rc == HG_OK; c++) {
+    const int32_t variant = c == 0 ? HG_VARIANT_FUSED : HG_VARIANT_PULL;
+    if (c == 0) {  // the fused schedule may not exist for this plan / width / workspace: skip it then
+      const hg::FusedSched *f = nullptr;
+      if (get_fused(plan, F, key & 1, &f) != HG_OK || fused_carve(*f, F).total > workspace_bytes) continue;
+    }
+    set_choice(variant, c == 0 ? 0 : c - 1);
+    for (int i = 0; i < 3 && rc == HG_OK; i++)
+      rc = aggr_impl(plan, F, csrptr_t, colind_t, X, degE, degV, W, Y, workspace, workspace_bytes, variant, stream, nullptr);
+    if (rc != HG_OK) break;
+    hipError_t he = hipEventRecord(e0, s);
+    for (int i = 0; i < iters && rc == HG_OK; i++)
+      rc = aggr_impl(plan, F, csrptr_t, colind_t, X, degE, degV, W, Y, workspace, workspace_bytes, variant, stream, nullptr);
+    if (he == hipSuccess) he = hipEventRecord(e1, s);
+    if (rc != HG_OK) break;
+    float ms = 0.f;
+    if (he == hipSuccess) he = hipEventSynchronize(e1);
+    if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
+    if (he != hipSuccess) {
+      rc = hip_fail("hg_plan_tune_f32: event timing", he);
+      break;
+    }
+    us[c] = ms * 1e3f / iters;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  int best = -1;
+  for (int c = 0; c < 5; c++)
+    if (us[c] >= 0.f && (best < 0 || us[c] < us[best])) best = c;
+  if (rc != HG_OK || best < 0) {  // leave the static rule in place
+    std::lock_guard<std::mutex> lock(mp->auto_mu);
+    mp->auto_choice.erase(key);
+    mp->hop_kernel.erase(F);
+    if (rc == HG_OK) {
+      hg::set_error("hg_plan_tune_f32: no candidate ran");
+      rc = HG_ERR_INVALID;
+    }
+    return rc;
+  }
+  // among the pull candidates keep the fastest hop kernels even if fused won: a forced HG_VARIANT_PULL uses them
+  int best_pull = 1;
+  for (int c = 2; c < 5; c++)
+    if (us[c] >= 0.f && us[c] < us[best_pull]) best_pull = c;
+  set_choice(best == 0 ? HG_VARIANT_FUSED : HG_VARIANT_PULL, best_pull - 1);
+  // Y holds the last candidate's result: run the winner once more so the caller gets what AUTO now computes
+  rc = aggr_impl(plan, F, csrptr_t, colind_t, X, degE, degV, W, Y, workspace, workspace_bytes, HG_VARIANT_AUTO, stream, nullptr);
+  if (info) {
+    info->variant = best == 0 ? HG_VARIANT_FUSED : HG_VARIANT_PULL;
+    info->pull_hop_kernels = best_pull - 1;
+    for (int c = 0; c < 5; c++) info->us[c] = us[c];
+    info->reserved = 0;
+  }
+  return rc;
 }
 
 int hg_linear_pack_f32(int32_t F_out, int32_t F_in, const float *Wlin, float *wfrag, hg_stream_t stream) {

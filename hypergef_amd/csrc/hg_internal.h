@@ -251,6 +251,7 @@ struct hg_plan {
   std::mutex stream_mu;
   int32_t stream_nslots[2] = {0, 0};  // partial rows a RowStream of each hop needs (independent of the lane layout)
   std::map<int64_t, int32_t> auto_choice;  // what HG_VARIANT_AUTO resolved to, keyed by (F, vec4)
+  std::map<int32_t, int32_t> hop_kernel;   // per F, set by hg_plan_tune_f32: bit h = pull hop h on the panel / task kernel
   std::mutex auto_mu;
   double small_nnz_frac = 0.0;  // share of incidences in hyperedges of <= t_big members
   int64_t device_bytes = 0;

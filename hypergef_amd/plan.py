@@ -124,6 +124,30 @@ class Plan:
             _lib.check(v)
         return {code: name for name, code in _lib.VARIANTS.items()}[v]
 
+    def tune(self, csrptr_t, colind_t, X, degE=None, degV=None, W=None, iters=20):
+        """Timed choice of what variant="auto" runs for X's width (hg_plan_tune_f32): the fused schedule and the
+        pull variant with either kernel per hop are run `iters` times each on these tensors and the fastest is
+        pinned -- the counterpart of the reference's tuner (HyperGAggr_tune, hgnnAgg.cuh:1115-1157), worth calling
+        for a single dataset-sized hypergraph.  Returns {"variant", "pull_hop_kernels", "us": {...}}."""
+        _check_feat(X, "node_feat")
+        F = X.shape[1]
+        self.prepare(F)
+        flat = lambda t: None if t is None else t.reshape(-1)
+        degE, degV, W = flat(degE), flat(degV), flat(W)
+        Y = torch.empty((self.N, F), dtype=torch.float32, device=X.device)
+        workspace, nbytes = self._workspace(F, X.device)
+        info = _lib.TuneInfo()
+        with torch.cuda.device(X.device):
+            _lib.check(_lib.lib().hg_plan_tune_f32(
+                self._h, F, _ptr(csrptr_t), _ptr(colind_t), _ptr(X), _ptr(degE), _ptr(degV), _ptr(W), _ptr(Y),
+                _ptr(workspace), nbytes, int(iters), _stream_handle(X.device), ctypes.byref(info)))
+        if hasattr(self, "_auto"):
+            self._auto.pop(F, None)  # the cached answer of auto_variant may have changed
+        names = {code: name for name, code in _lib.VARIANTS.items()}
+        labels = ("fused", "pull", "pull/hop0-panels", "pull/hop1-panels", "pull/panels")
+        return {"variant": names[info.variant], "pull_hop_kernels": info.pull_hop_kernels,
+                "us": {l: float(u) for l, u in zip(labels, info.us) if u >= 0}}
+
     def workspace_bytes(self, F):
         return int(_lib.lib().hg_plan_workspace_bytes(self._h, F))
 

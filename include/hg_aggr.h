@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HG_AGGR_VERSION 200 /* major*10000 + minor*100 + patch */
+#define HG_AGGR_VERSION 201 /* major*10000 + minor*100 + patch */
 
 #if defined(__GNUC__)
 #define HG_API __attribute__((visibility("default")))
@@ -198,6 +198,25 @@ HG_API int hg_plan_bind_scales(const hg_plan *plan, int32_t F, const float *degE
 /* The variant HG_VARIANT_AUTO resolves to for feature width F (builds the
  * F-dependent schedule if the choice needs it); negative hg_status on error. */
 HG_API int hg_plan_auto_variant(const hg_plan *plan, int32_t F);
+/* Timed choice for feature width F, the counterpart of the reference's tuner (HyperGAggr_tune,
+ * include/hgnnAgg.cuh:1115-1157: it times 20 partition sizes and keeps the fastest).  Runs the candidates on
+ * the caller's buffers -- the fused schedule, and the pull variant with either kernel for each hop (streaming
+ * row gather / panels + wave tasks) -- `iters` times each between two events on `stream`, waits for them, and
+ * pins what HG_VARIANT_AUTO does for this width from then on.  Matters on launch-bound graphs (one dataset-sized
+ * hypergraph), where the static rule cannot see which kernel's dependent round trips are shorter.  Same
+ * arguments as hg_aggr_fused_f32 (Y ends up holding the result); workspace as after hg_plan_prepare.  The
+ * candidates differ in summation order, so the low bits of later AUTO results depend on which one won; do not
+ * call it while other threads use the plan.  info may be NULL. */
+typedef struct hg_tune_info {
+  int32_t variant;           /* HG_VARIANT_FUSED or HG_VARIANT_PULL */
+  int32_t pull_hop_kernels;  /* bit h set: pull hop h (0: vertices -> hyperedges) runs on the panel / task kernel */
+  float us[5];               /* microseconds per call: fused, pull with hop kernels 0 .. 3 (negative: not run) */
+  int32_t reserved;
+} hg_tune_info;
+HG_API int hg_plan_tune_f32(const hg_plan *plan, int32_t F, const int32_t *csrptr_t, const int32_t *colind_t,
+                            const float *X, const float *degE, const float *degV, const float *W, float *Y,
+                            void *workspace, size_t workspace_bytes, int32_t iters, hg_stream_t stream,
+                            hg_tune_info *info);
 /* Host copy of one hop's schedule as int32 quadruples (tests, tools): panels
  * {row0, nrows, nnz0, nnz_cnt}, tasks {row, beg, end, slot}, fixups {row,
  * first_slot, count, 0}; sizes from hg_plan_get_info.  Pointers may be NULL. */

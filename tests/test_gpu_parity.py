@@ -348,7 +348,8 @@ def test_aggr_proto_cli_gpu(hg, tmp_path):
         assert r.returncode == 0, r.stdout + r.stderr
         out = r.stdout
         assert "check failed!" not in out and "Wrong result" not in out
-        assert out.count("check passed!") == 4  # rocSPARSE two-step, edge-fused, pull, fused
+        assert out.count("check passed!") == 5  # rocSPARSE two-step, edge-fused, pull, fused, tuned auto
+        assert "tuned auto (" in out
         for needle in ("The time of two rocsparse spmm", "test time one baseline fused kernel:",
                        "test ef full tune time one", "test ef shm tune time one", "within 1e-5"):
             assert needle in out, out
@@ -1204,3 +1205,36 @@ def test_random_graphs_widths_and_options_differential(hg, oracle, seed):
                 bad = np.abs(y - truth) > 1e-5 * np.maximum(1.0, mass)
                 assert not bad.any(), (seed, inc.name, F, shift, variant, weighted, int(bad.sum()), np.argwhere(bad)[:3])
                 np.testing.assert_allclose(y, ref, rtol=2e-3, atol=1e-5 * float(np.abs(mass).max()))
+
+
+@pytest.mark.parametrize("dname", ["house-committees", "pubmed", "zoo", "cora"])
+def test_timed_choice_pins_auto_and_keeps_results(hg, oracle, dname):
+    """hg_plan_tune_f32 (the reference's HyperGAggr_tune, hgnnAgg.cuh:1115-1157, on this backend's candidates):
+    every candidate is timed on the caller's tensors, the winner becomes what "auto" runs for that width, the
+    pull hops keep the kernels that were fastest, and the results stay those of the operator -- weighted and
+    unweighted, whatever won."""
+    from hypergef_amd.plan import Plan
+    inc = synth.allset_shape(dname)
+    F = 32
+    X, degE, degV, W, H_ptr, H_ind = _inputs(inc, F, oracle, seed=5)
+    degE = np.where(np.isinf(degE), 0, degE).astype(np.float32)
+    ptr, ind, Xd = _dev(inc.csrptr), _dev(inc.colind), _dev(X)
+    plan = Plan.from_tensors(inc.N, ptr, ind)
+    before = plan.auto_variant(F)
+    info = plan.tune(ptr, ind, Xd, iters=10)
+    assert info["variant"] in ("fused", "pull") and 0 <= info["pull_hop_kernels"] <= 3
+    assert "pull" in info["us"] and len(info["us"]) >= 4 and all(u > 0 for u in info["us"].values())
+    assert plan.auto_variant(F) == info["variant"], (before, info)
+    best = min(info["us"], key=info["us"].get)
+    assert (best == "fused") == (info["variant"] == "fused")
+    ref = oracle.hyperaggr_host(inc.N, F, H_ptr, H_ind, inc.csrptr, inc.colind, X)
+    mass = _float64_truth(inc, np.abs(X))
+    for variant in ("auto", "pull", "fused"):
+        y = plan.aggregate(ptr, ind, Xd, variant=variant).cpu().numpy()
+        assert (np.abs(y - _float64_truth(inc, X)) <= 1e-5 * np.maximum(1.0, mass)).all(), (dname, variant)
+        np.testing.assert_allclose(y, ref, rtol=1e-4, atol=1e-5)
+    refw = oracle.hgnn_check(inc.N, inc.M, F, H_ptr, H_ind, inc.csrptr, inc.colind, X, degE, degV, W)
+    info_w = plan.tune(ptr, ind, Xd, _dev(degE), _dev(degV), _dev(W), iters=5)
+    yw = plan.aggregate(ptr, ind, Xd, _dev(degE), _dev(degV), _dev(W)).cpu().numpy()
+    np.testing.assert_allclose(yw, refw, rtol=1e-4, atol=1e-5)
+    assert info_w["variant"] == plan.auto_variant(F)

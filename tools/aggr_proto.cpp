@@ -323,6 +323,22 @@ int main(int argc, char **argv) {
         best_v = variants[i];
       }
     }
+    {  // the timed choice (hg_plan_tune_f32: the reference's HyperGAggr_tune on this backend's candidates), then "auto"
+      hg_tune_info ti;
+      HG_OKAY(hg_plan_tune_f32(plan, F, dTp, dTi, dX, nullptr, nullptr, nullptr, dY, ws, wsb, 20, nullptr, &ti));
+      if (validate("tuned auto")) {
+        tm.start();
+        for (int k = 0; k < iter_fused; k++)
+          HG_OKAY(hg_aggr_fused_f32(plan, F, dTp, dTi, dX, nullptr, nullptr, nullptr, dY, ws, wsb, HG_VARIANT_AUTO, nullptr));
+        const float t = tm.stop() / iter_fused;
+        printf("  tuned auto (%s, pull hop kernels %d): %.4f ms (%.3g G edges/s)\n",
+               ti.variant == HG_VARIANT_FUSED ? "fused" : "pull", ti.pull_hop_kernels, t, (double)nnz / t / 1e6);
+        if (t < best) {
+          best = t;
+          best_v = ti.variant;
+        }
+      }
+    }
     printf("test ef shm tune time one %.4f ms\n", best);
     fs << best << "," << best_v << ",";
     HIP_OK(hipFree(ws));
