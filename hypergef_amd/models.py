@@ -51,8 +51,18 @@ class HyperGsysUinGINConv(nn.Module):
     def forward(self, X):
         if ops._STATE["variant"] in ("auto", "pull", "fused") and ops.linear_fusion_pays(X.shape[1], self.W.weight.shape[0]):
             # (1 + eps) W(X) + Aggr(W(X)) = ((1 + eps) X + Aggr(X)) . W^T: the whole layer in one pass
+            # training: cb stays a tensor (eps is learned: its gradient flows through cb, and reading the value
+            # costs one device-to-host copy per step); without grad the value is read once per eps update and
+            # handed over as a Python float -- no sync in the forward, so the forward can be captured in a hipGraph
+            if torch.is_grad_enabled() and self.eps.requires_grad:
+                cb = 1 + self.eps.reshape(())
+            else:
+                key = (self.eps.data_ptr(), self.eps._version)
+                if getattr(self, "_eps_host", (None, 0.0))[0] != key:
+                    self._eps_host = (key, float(self.eps.detach()))
+                cb = 1.0 + self._eps_host[1]
             return ops.aggr_res_linear(self.hyperg.H_T_csrptr, self.hyperg.H_T_colind, X, self.W.weight,
-                                       residual=X, ca=1.0, cb=1 + self.eps.reshape(()))
+                                       residual=X, ca=1.0, cb=cb)
         X = self.W(X)
         Xv = UniGNNConv(self.hyperg, X)
         return (1 + self.eps) * X + Xv

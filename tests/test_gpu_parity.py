@@ -871,10 +871,13 @@ def test_config5_driver_runs_on_hip_backend(hg, model, tmp_path):
     out = tmp_path / "o.csv"
     cmd = [sys.executable, os.path.join(ROOT, "tools", "ugsys.py"), "--backend", "hgsys", "--model-name", model,
            "--dname", "cora", "--epochs", "2", "--replicas", "4", "--nlayer", "3", "--nhid", "64",
-           "--output", str(out)]
+           "--output", str(out), "--graph"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "backend hgsys: avg epoch time" in r.stdout and "avg inference time" in r.stdout
+    # --graph: the whole forward captured in one hipGraph (no host sync, no allocation outside the graph's pool in
+    # any layer) and replayed; the driver itself checks the replay against the eager forward
+    assert "as a hipGraph replay" in r.stdout
     assert out.read_text().startswith("hgsys,%s,cora,nlayer=3" % model)
 
 

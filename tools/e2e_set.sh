@@ -10,4 +10,10 @@ for b in hgsys torch; do python tools/hgsys.py --model HGNN --backend $b --dname
 for m in UniGCNII UniGIN; do for b in hgsys torch; do
   python tools/hgsys.py --model $m --backend $b --dname cora --replicas 256 --nhid 64 --nlayer 8 --nfeat 64 --epochs 20 --output $out > /dev/null 2>&1
 done; done
-cat $out
+# launch-bound models (one dataset-sized hypergraph): inference as one hipGraph replay per forward
+g=${out%.csv}_graph.csv; rm -f $g
+for m in HGNN UniGIN UniGCNII; do for b in hgsys torch; do
+  python tools/hgsys.py --model $m --backend $b --dname cora --epochs 100 --graph --output $g > /dev/null 2>&1
+done; done
+for b in hgsys torch; do python tools/hgsys.py --model HGNN --backend $b --dname pubmed --nhid 128 --epochs 100 --graph --output $g > /dev/null 2>&1; done
+cat $out; echo "-- with --graph (last column: hipGraph replay)"; cat $g
