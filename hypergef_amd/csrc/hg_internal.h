@@ -90,7 +90,7 @@ struct HubPass {
   // that hyperedge sum add it to a register of its own; the lane groups' registers are added up
   // once, at the end of the launch.  No tile read, no list entry, perfectly balanced.
   int32_t n_heavy = 0;
-  int32_t hslot0[kHubHeavy] = {-1, -1, -1, -1};  // first partial row of each heavy hub (+ workgroup id)
+  int32_t hslot0[kHubHeavy] = {};  // first partial row of each heavy hub (+ workgroup id)
   int32_t nv = 0;   // virtual rows in use (<= ng * R)
   int32_t bs = 1024, ng = 0, R = kHubRows;
   int32_t cap = 0, mem_cap = 0, pair_cap = 0;  // per round: slots, stream entries, (row, slot) pairs

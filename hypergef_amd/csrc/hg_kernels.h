@@ -86,7 +86,7 @@ struct HubArgs {
   int32_t F;
   int32_t x_bytes, mat_bytes, nrows_x, nrows_mat;
   int32_t n_heavy = 0;  // hubs fed by stream flags (bits 24..27 of a slot's last entry)
-  int32_t hslot0[kHubHeavy] = {-1, -1, -1, -1};  // their first partial rows
+  int32_t hslot0[kHubHeavy] = {};  // their first partial rows
   int32_t debug = 0;    // ablation bits, diagnostic build only
 };
 
