@@ -277,20 +277,30 @@ __global__ __launch_bounds__(256) void fixup_rows_kernel(const GatherArgs a, con
 // -DHG_STAMPS, then HG_FUSED_DEBUG bit 32); the production kernels carry no stamp code.
 __device__ unsigned long long hg_stamps[8];
 #ifdef HG_STAMPS
-#define HG_STAMP_INIT(cond)                                                  \
-  const bool stamp = ((a.debug & 32) != 0) && (cond) && (threadIdx.x & 63) == 0; \
+// ticks are summed per wave (scalar registers) and added to the global counters once, at HG_STAMP_FLUSH: one
+// atomic per phase and wave -- an atomic at every stamp serialises thousands of waves on six addresses and
+// ends up measuring itself
+#define HG_STAMP_INIT(cond)                                  \
+  const bool stamp = ((a.debug & 32) != 0) && (cond);        \
+  unsigned long long st_[6] = {0, 0, 0, 0, 0, 0};            \
   unsigned long long t0 = stamp ? __builtin_amdgcn_s_memtime() : 0
 #define HG_STAMP(i)                                                        \
   do {                                                                     \
     if (stamp) {                                                           \
       const unsigned long long t1 = __builtin_amdgcn_s_memtime();          \
-      atomicAdd(&hg_stamps[i], t1 - t0);                                   \
+      st_[i] += t1 - t0;                                                   \
       t0 = t1;                                                             \
     }                                                                      \
+  } while (0)
+#define HG_STAMP_FLUSH()                                                   \
+  do {                                                                     \
+    if (stamp && (threadIdx.x & 63) == 0)                                  \
+      for (int i_ = 0; i_ < 6; i_++) atomicAdd(&hg_stamps[i_], st_[i_]);   \
   } while (0)
 #else
 #define HG_STAMP_INIT(cond) do { } while (0)
 #define HG_STAMP(i) do { } while (0)
+#define HG_STAMP_FLUSH() do { } while (0)
 #endif
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the
@@ -877,6 +887,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LIN ? (LPR 
     }
   }
   HG_STAMP(5);
+  HG_STAMP_FLUSH();
 }
 
 
@@ -935,6 +946,7 @@ __global__ __launch_bounds__(1024) void hub_pass_kernel(const HubArgs a) {
   [[maybe_unused]] const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float *>(a.Xe_mat ? a.Xe_mat : a.X), 0, (a.Xe_mat && !HG_HUB_ABLATE(4)) ? a.mat_bytes : 0, 0x00020000);
   const int rd0 = a.wg_first[w], rd1 = a.wg_first[w + 1];
+  HG_STAMP_INIT(true);
   // A record is at most NPRE * 16 KB: each thread carries NPRE dwordx4 of the NEXT round's record
   // through hop 1, so the copy's round trip hides behind the row gathers.
   constexpr int NPRE = 2;
@@ -959,6 +971,7 @@ __global__ __launch_bounds__(1024) void hub_pass_kernel(const HubArgs a) {
   int cur = 0;
   if (rd0 < rd1) stash(recbuf, fetch(rd0));
   __syncthreads();
+  HG_STAMP(0);
   for (int rd = rd0; rd < rd1; rd++) {
     const int32_t *rec = recbuf + cur * a.max_rec_words;
     int n4_next = 0;
@@ -978,6 +991,7 @@ __global__ __launch_bounds__(1024) void hub_pass_kernel(const HubArgs a) {
     const int32_t *stream = rec + rec[5];
     const uint16_t *pend = reinterpret_cast<const uint16_t *>(rec + rec[6]);
     const uint16_t *pvs = reinterpret_cast<const uint16_t *>(rec + rec[9]);
+    HG_STAMP(1);
     if (!HG_HUB_ABLATE(1)) {  // ---- hop 1: this round's hyperedge sums -> tile (and heavy hubs' registers)
       [[maybe_unused]] int slot = gbase[g];
       float *tp = tile + gbase[g] * TW + lcol;
@@ -1032,8 +1046,10 @@ __global__ __launch_bounds__(1024) void hub_pass_kernel(const HubArgs a) {
         if (s0 < steps) block(s0, steps, std::false_type{}, std::true_type{});
       }
     }
+    HG_STAMP(2);
     stash(recbuf + (cur ^ 1) * a.max_rec_words, n4_next);  // nobody reads that buffer during this round
     __syncthreads();
+    HG_STAMP(3);
     // ---- hop 2: every virtual row adds the tile rows of the hyperedges it belongs to
     if (!HG_HUB_ABLATE(2)) {
       // the lane group's R cumulative ends: eight aligned dwords of 16-bit pairs (g * R is a multiple of 16)
@@ -1065,7 +1081,9 @@ __global__ __launch_bounds__(1024) void hub_pass_kernel(const HubArgs a) {
         }
       }
     }
+    HG_STAMP(4);
     __syncthreads();  // the tile is rewritten by the next round, this record by the one after
+    HG_STAMP(5);
     cur ^= 1;
   }
 #pragma unroll
@@ -1089,6 +1107,7 @@ __global__ __launch_bounds__(1024) void hub_pass_kernel(const HubArgs a) {
       __syncthreads();
     }
   }
+  HG_STAMP_FLUSH();
 }
 
 // Streaming row gather (RowStream, hg_internal.h): dst[r] = scaleB * (scaleA * sum of the src rows of CSR
