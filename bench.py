@@ -79,7 +79,7 @@ def parse():
     p.add_argument("--sharded-nodes", type=int, default=1_000_000, help="N > 1: the one hypergraph that is sharded")
     p.add_argument("--sharded-edges", type=int, default=4_000_000)
     p.add_argument("--sharded-feat", type=int, default=64)
-    p.add_argument("--sharded-chunks", type=int, default=4, help="column slices of the pipelined all-reduce")
+    p.add_argument("--sharded-chunks", type=int, default=2, help="column slices of the pipelined all-reduce")
     p.add_argument("--share-gpu", action="store_true",
                    help="rehearse the N>1 path on one GPU: all ranks use cuda:0, gloo instead of RCCL")
     return p.parse_args()
@@ -369,7 +369,7 @@ def sharded_section(args, dev, sync, barrier, rank, world):
         full = Plan.from_tensors(inc.N, ptr, ind).aggregate(ptr, ind, X)
     for exchange in ("allreduce", "reduce_scatter", "allreduce_pipelined"):
         try:
-            if exchange == "allreduce_pipelined":  # SURVEY 8(e) iv: 4 column slices, collective c overlaps kernels c + 1
+            if exchange == "allreduce_pipelined":  # SURVEY 8(e) iv: column slices, collective c overlaps kernels c + 1
                 agg = ShardedAggregator(inc, device=dev, exchange="allreduce", column_chunks=args.sharded_chunks)
             else:
                 agg = ShardedAggregator(inc, device=dev, exchange=exchange)
