@@ -10,7 +10,7 @@ import numpy as np, torch
 from hypergef_amd import plan as planmod, synth, _lib
 dev = "cuda:0"
 K, F = int(os.environ.get("STAMP_K", "1024")), int(os.environ.get("STAMP_F", "32"))
-inc = synth.replicate_block_diagonal(synth.cora_shape(), K)
+inc = synth.powerlaw(1_000_000, 4_000_000, seed=3) if os.environ.get("STAMP_SHAPE") == "powerlaw" else synth.replicate_block_diagonal(synth.cora_shape(), K)
 ptr, ind = torch.from_numpy(inc.csrptr).to(dev), torch.from_numpy(inc.colind).to(dev)
 X = torch.rand(inc.N, F, device=dev)
 plan = planmod.Plan.from_tensors(inc.N, ptr, ind)
@@ -31,7 +31,7 @@ names = os.environ.get("STAMP_NAMES", "descriptor,record copy (+scale reads),bar
 tot = sum(buf[i] for i in range(6))
 info = plan.prepare(F)
 waves = info["panels"] * 4 * n
-clk = 1e8  # s_memtime ticks at 100 MHz on this part
+clk = 1e8  # nominal: the tick is the shader clock here, so the us column is only relative
 for i, nm in enumerate(names):
     print("%-28s %6.1f %%   %8.3f us/wave" % (nm, 100.0 * buf[i] / tot, buf[i] / waves / clk * 1e6))
 print("F=%d panels %d cap %d: total us/wave %.3f" % (F, info["panels"], info["cap"], tot / waves / clk * 1e6))
