@@ -195,8 +195,14 @@ void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_
       while (hp.n_heavy < kHubHeavy && hp.n_heavy < (int32_t)cand.size() && deg(cand[hp.n_heavy]) >= kHubMinDeg &&
              (int64_t)deg(cand[hp.n_heavy]) * 512 >= nnz)
         heavy_sum += deg(cand[hp.n_heavy++]);
-      // no virtual row heavier than half a lane group's fair share of a round
-      const int64_t wmax = std::max<int64_t>(1, (top - heavy_sum) / (2 * (int64_t)hp.ng));
+      // A wave's hop 2 costs, per chunk of kHubChunk rows, the LONGEST list among the chunk's rows of all its lane
+      // groups (lockstep), so the heaviest virtual row sets the critical path of every round: cut the big hubs into
+      // parts of at most a sixth of a lane group's fair share (the lightest hubs that no longer fit become pieces).
+      // Modelled on the power-law config (critical path of a round, incidences): parts of 1/2 share + least-loaded
+      // assignment 75.8 k; 1/6 share + the sorted assignment below 34.2 k (ideal 34 k).  Measured: hop 2 of a round
+      // 5726 -> 4662 ticks, step 0.957 -> 0.949 ms -- a round's lists are only a few entries long, so their fixed
+      // latency (two dependent LDS reads per entry) outweighs their balance.
+      const int64_t wmax = std::max<int64_t>(1, (top - heavy_sum) / (6 * (int64_t)hp.ng));
       int32_t nv = 0;
       for (size_t i = 0; i < cand.size() && deg(cand[i]) >= kHubMinDeg; i++) {
         const bool heavy = (int32_t)i < hp.n_heavy;
@@ -433,17 +439,17 @@ static void build_hub_pass(int32_t N, int32_t M, const int32_t *ptr_t, const int
     for (int32_t j = 0; j < parts[h]; j++) vr.push_back(VRow{h, j, (d + parts[h] - 1) / parts[h]});
   }
   std::stable_sort(vr.begin(), vr.end(), [](const VRow &a, const VRow &b) { return a.w > b.w; });
-  std::vector<int64_t> gload((size_t)ng, 0);
-  std::vector<int32_t> gcount((size_t)ng, 0);
   std::vector<int32_t> part0((size_t)hp.K + 1, 0);  // first index of each hub's parts in vrow_id
   for (int32_t h = 0; h < hp.K; h++) part0[h + 1] = part0[h] + parts[h];
   std::vector<int32_t> vrow_id((size_t)part0[hp.K], -1);  // (hub, part) -> group * R + i
-  for (const VRow &x : vr) {
-    int32_t best = -1;
-    for (int32_t g = 0; g < ng; g++)
-      if (gcount[g] < R && (best < 0 || gload[g] < gload[best])) best = g;
-    vrow_id[part0[x.hub] + x.part] = best * R + gcount[best]++;
-    gload[best] += x.w;
+  // Rows of like weight share a chunk, and neighbouring chunks go to neighbouring lane groups (the same wave):
+  // kHubChunk consecutive rows of the sorted list fill chunk c of group k, the groups walked back and forth
+  // from one chunk level to the next so that every group gets a heavy, a middling and a light chunk.
+  static_assert(kHubRows % kHubChunk == 0, "chunks tile the rows of a lane group");
+  for (size_t i = 0; i < vr.size(); i++) {
+    const int32_t q = (int32_t)(i / kHubChunk), c = q / ng, k = q % ng;
+    const int32_t g = (c & 1) ? ng - 1 - k : k;
+    vrow_id[part0[vr[i].hub] + vr[i].part] = g * R + c * kHubChunk + (int32_t)(i % kHubChunk);
   }
 
   // rounds

@@ -74,6 +74,7 @@ struct FRec {
 // A hub with a large share of the incidences is cut into several virtual rows ("parts", its
 // incidences dealt round-robin) so that no lane group becomes the critical path of a round.
 constexpr int kHubRows = 12;   // virtual hub rows per lane group of the hub pass (accumulator registers)
+constexpr int kHubChunk = 4;  // virtual rows a lane group walks together in hop 2 (kRows is a multiple of it)
 constexpr int kHubHeavy = 4;  // heavy hubs fed by stream flags: four accumulators per lane (registers are what limits it)
 
 struct HubRec {

@@ -1059,7 +1059,7 @@ __global__ __launch_bounds__(1024) void hub_pass_kernel(const HubArgs a) {
       for (int i = 0; i < R / 2; i++) ew[i] = pw[i];
       const int first = g ? (int)(pw[-1] >> 16) : 0;
       auto end_of = [&](int i) { return (int)((ew[i >> 1] >> ((i & 1) * 16)) & 0xffffu); };  // i static
-      constexpr int C = 4;  // rows walked together: four (index, tile row) pairs in flight per lane group
+      constexpr int C = kHubChunk;  // rows walked together: four (index, tile row) pairs in flight per lane group
 #pragma unroll
       for (int c = 0; c < R; c += C) {
         int b_[C], n_[C], len = 0;
