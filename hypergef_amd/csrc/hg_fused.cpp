@@ -195,14 +195,12 @@ void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_
       while (hp.n_heavy < kHubHeavy && hp.n_heavy < (int32_t)cand.size() && deg(cand[hp.n_heavy]) >= kHubMinDeg &&
              (int64_t)deg(cand[hp.n_heavy]) * 512 >= nnz)
         heavy_sum += deg(cand[hp.n_heavy++]);
-      // A wave's hop 2 costs, per chunk of kHubChunk rows, the LONGEST list among the chunk's rows of all its lane
-      // groups (lockstep), so the heaviest virtual row sets the critical path of every round: cut the big hubs into
-      // parts of at most a sixth of a lane group's fair share (the lightest hubs that no longer fit become pieces).
-      // Modelled on the power-law config (critical path of a round, incidences): parts of 1/2 share + least-loaded
-      // assignment 75.8 k; 1/6 share + the sorted assignment below 34.2 k (ideal 34 k).  Measured: hop 2 of a round
-      // 5726 -> 4662 ticks, step 0.957 -> 0.949 ms -- a round's lists are only a few entries long, so their fixed
-      // latency (two dependent LDS reads per entry) outweighs their balance.
-      const int64_t wmax = std::max<int64_t>(1, (top - heavy_sum) / (6 * (int64_t)hp.ng));
+      // no virtual row heavier than half a lane group's fair share of a round.  (A wave's hop 2 costs, per chunk
+      // of kHubChunk rows, the longest list among the chunk's rows of all its lane groups, so smaller parts shorten a
+      // round's critical path -- modelled 75.8 k -> 34.2 k incidences with a sixth of a share -- but every hub that
+      // loses its register row to them comes back as pieces in the panels: measured with the sorted assignment of
+      // build_hub_pass, power-law F = 64: 1/2 share 0.924 ms, 1/3 0.926, 1/6 0.941.)
+      const int64_t wmax = std::max<int64_t>(1, (top - heavy_sum) / (2 * (int64_t)hp.ng));
       int32_t nv = 0;
       for (size_t i = 0; i < cand.size() && deg(cand[i]) >= kHubMinDeg; i++) {
         const bool heavy = (int32_t)i < hp.n_heavy;
