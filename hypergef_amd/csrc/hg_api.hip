@@ -176,7 +176,8 @@ int get_fused(const hg_plan *cp, int32_t F, bool vec4, const hg::FusedSched **ou
   const int32_t ng = 256 / (row_floats / (vec4 ? 4 : 1));  // lane groups per workgroup
   // The hub pass reads X and the materialised table through buffer descriptors (row index below 2^24,
   // tables below 2 GiB) and exists for 16-byte lanes of at least 16 floats per row.
-  const bool allow_hub = vec4 && F % 4 == 0 && F >= 16 && p->N < (1 << 24) && (int64_t)p->N * F * 4 < ((int64_t)1 << 31) &&
+  // (rows of the materialised table are masked to 24 bits in the round records too, and n_mat <= M)
+  const bool allow_hub = vec4 && F % 4 == 0 && F >= 16 && p->N < (1 << 24) && p->M < (1 << 24) && (int64_t)p->N * F * 4 < ((int64_t)1 << 31) &&
                          (int64_t)p->M * F * 4 < ((int64_t)1 << 31);
   const int64_t key = (((int64_t)cap * 1000000 + mem_cap) * 1000 + ng) * 2 + (allow_hub ? 1 : 0);
   std::lock_guard<std::mutex> lock(p->fused_mu);
@@ -283,9 +284,10 @@ FusedCarve fused_carve(const hg::FusedSched &f, int32_t F) {
 }
 // The pull layout always fits a pull call; a fused schedule that exists for this width (built by
 // hg_plan_prepare, hg_plan_auto_variant or an earlier call) may need more for its partial rows.
-size_t workspace_need(const hg_plan *cp, int32_t F) {
+size_t workspace_need(const hg_plan *cp, int32_t F, bool pull_only = false) {
   hg_plan *p = const_cast<hg_plan *>(cp);
   size_t need = carve(p, F).total;
+  if (pull_only) return need;
   std::lock_guard<std::mutex> lock(p->fused_mu);
   for (const auto &kv : p->fused_by_width)
     if (kv.first / 2 == F) need = std::max(need, fused_carve(*kv.second, F).total);
@@ -466,7 +468,10 @@ int run_hop(const hg_plan *p, int hop, int32_t F, const int32_t *ptr, const int3
                    stream);
 }
 
-int check_call(const hg_plan *plan, int32_t F, const void *workspace, size_t workspace_bytes) {
+// pull_only: the call runs the pull layout whatever schedules exist (a forced HG_VARIANT_PULL, a single hop): a
+// caller-owned workspace that was large enough before a fused schedule was built stays valid for such calls.
+enum { kSizeAny = 0, kSizePull = 1, kSizeLater = 2 };  // kSizeLater: the caller checks once it knows which layout runs
+int check_call(const hg_plan *plan, int32_t F, const void *workspace, size_t workspace_bytes, int size_mode = kSizeAny) {
   if (!plan) {
     hg::set_error("null plan");
     return HG_ERR_INVALID;
@@ -483,7 +488,7 @@ int check_call(const hg_plan *plan, int32_t F, const void *workspace, size_t wor
     hg::set_error("feature matrix too large");
     return HG_ERR_INVALID;
   }
-  const size_t need = workspace_need(plan, F);
+  const size_t need = size_mode == kSizeLater ? 0 : workspace_need(plan, F, size_mode == kSizePull);
   if (need > 0 && (!workspace || workspace_bytes < need)) {
     hg::set_error("workspace too small: need " + std::to_string(need) + " bytes, got " +
                   std::to_string(workspace_bytes));
@@ -795,7 +800,7 @@ int hg_gather_rows_f32(const hg_plan *plan, int32_t hop, int32_t F, const int32_
                        const int32_t *colind_t, const float *src, const float *scaleA,
                        const float *scaleB, float *dst, void *workspace, size_t workspace_bytes,
                        hg_stream_t stream) {
-  int rc = check_call(plan, F, workspace, workspace_bytes);
+  int rc = check_call(plan, F, workspace, workspace_bytes, kSizePull);
   if (rc != HG_OK) return rc;
   if ((hop != 0 && hop != 1) || !src || !dst || (hop == 0 && (!csrptr_t || (plan->nnz > 0 && !colind_t)))) {
     hg::set_error("hg_gather_rows_f32: bad argument");
@@ -898,7 +903,8 @@ static int aggr_impl(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
     hg::set_error("hg_aggr_fused_f32: unknown variant");
     return HG_ERR_UNSUPPORTED;
   }
-  int rc = check_call(plan, F, workspace, workspace_bytes);
+  // the size is checked against the layout that actually runs, once the variant is resolved
+  int rc = check_call(plan, F, workspace, workspace_bytes, kSizeLater);
   if (rc != HG_OK) return rc;
   if (!csrptr_t || (plan->nnz > 0 && !colind_t) || !X || !Y) {
     hg::set_error("hg_aggr_fused_f32: null array");
@@ -917,7 +923,7 @@ static int aggr_impl(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
   if (variant == HG_VARIANT_FUSED) {
     if (!f && (rc = get_fused(plan, F, vec4, &f)) != HG_OK) return rc;
     const FusedCarve fc = fused_carve(*f, F);
-    if (fc.total > workspace_bytes) {
+    if (fc.total > 0 && (!workspace || fc.total > workspace_bytes)) {
       hg::set_error("workspace too small for the fused schedule: need " + std::to_string(fc.total) + " bytes, got " +
                     std::to_string(workspace_bytes) +
                     " (hg_plan_workspace_bytes covers it once hg_plan_prepare has built the schedule)");
@@ -1032,6 +1038,10 @@ static int aggr_impl(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
       if (e != hipSuccess) return hip_fail("fixup launch", e);
     }
     return HG_OK;
+  }
+  if (c.total > 0 && (!workspace || workspace_bytes < c.total)) {
+    hg::set_error("workspace too small: need " + std::to_string(c.total) + " bytes, got " + std::to_string(workspace_bytes));
+    return HG_ERR_WORKSPACE;
   }
   // hop 1: Xe[e] = ((sum_{u in e} X[u]) * degE[e]) * W[e]
   rc = run_hop(plan, 0, F, csrptr_t, colind_t, X, degE, W, Xe,

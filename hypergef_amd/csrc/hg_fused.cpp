@@ -191,10 +191,22 @@ void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_
     for (size_t i = 0; i < cand.size() && (int32_t)i < vmax && deg(cand[i]) >= kHubMinDeg; i++) top += deg(cand[i]);
     if (top * 5 >= nnz) {  // the pass streams (nearly) every hyperedge: worth it for a fifth of the incidences
       // the heaviest few (each at least 1/512 of all incidences) ride on stream flags, not on virtual rows
+      // A flag bit says "this hyperedge contains the hub", once: a vertex listed twice in some hyperedge (duplicate
+      // incidences are legal input) keeps virtual rows, whose pair lists carry one pair per incidence.  The heavy
+      // ones move to the front of `cand`, so that hub ids [0, n_heavy) are exactly the flag-fed hubs.
+      auto listed_twice = [&](int32_t v) {  // a vertex's hyperedges are ascending (stable transpose)
+        for (int32_t p = ptr_v[v] + 1; p < ptr_v[v + 1]; p++)
+          if (ind_v[p] == ind_v[p - 1]) return true;
+        return false;
+      };
       int64_t heavy_sum = 0;
-      while (hp.n_heavy < kHubHeavy && hp.n_heavy < (int32_t)cand.size() && deg(cand[hp.n_heavy]) >= kHubMinDeg &&
-             (int64_t)deg(cand[hp.n_heavy]) * 512 >= nnz)
-        heavy_sum += deg(cand[hp.n_heavy++]);
+      for (size_t i = 0; i < cand.size() && hp.n_heavy < kHubHeavy && deg(cand[i]) >= kHubMinDeg &&
+                         (int64_t)deg(cand[i]) * 512 >= nnz; i++) {
+        if (listed_twice(cand[i])) continue;
+        heavy_sum += deg(cand[i]);
+        std::rotate(cand.begin() + hp.n_heavy, cand.begin() + i, cand.begin() + i + 1);
+        hp.n_heavy++;
+      }
       // no virtual row heavier than half a lane group's fair share of a round.  (A wave's hop 2 costs, per chunk
       // of kHubChunk rows, the longest list among the chunk's rows of all its lane groups, so smaller parts shorten a
       // round's critical path -- modelled 75.8 k -> 34.2 k incidences with a sixth of a share -- but every hub that

@@ -148,6 +148,13 @@ class Plan:
         return {"variant": names[info.variant], "pull_hop_kernels": info.pull_hop_kernels,
                 "us": {l: float(u) for l, u in zip(labels, info.us) if u >= 0}}
 
+    def _ensure_fused(self, F):
+        if not hasattr(self, "_prepared"):
+            self._prepared = set()
+        if F not in self._prepared:
+            self.prepare(F)
+            self._prepared.add(F)
+
     def workspace_bytes(self, F):
         return int(_lib.lib().hg_plan_workspace_bytes(self._h, F))
 
@@ -174,6 +181,8 @@ class Plan:
         if (degE is not None or degV is not None or W is not None) and variant in ("auto", "fused"):
             self._bind_scales(F, degE, degV, W, X.device, bind_scales)
         Y = out if out is not None else torch.empty((self.N, F), dtype=torch.float32, device=X.device)
+        if variant == "fused":  # hg_plan_workspace_bytes sizes for what AUTO runs; a forced fused call needs its schedule first
+            self._ensure_fused(F)
         if workspace is None:
             workspace, nbytes = self._workspace(F, X.device)
         else:
@@ -214,6 +223,8 @@ class Plan:
         if (degE is not None or degV is not None or W is not None) and variant in ("auto", "fused"):
             self._bind_scales(F_in, degE, degV, W, X.device, bind_scales)
         Y = out if out is not None else torch.empty((self.N, F_out), dtype=torch.float32, device=X.device)
+        if variant == "fused":
+            self._ensure_fused(F_in)
         if workspace is None:
             nbytes = int(_lib.lib().hg_aggr_linear_workspace_bytes(self._h, F_in))
             workspace = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=X.device)
@@ -356,14 +367,22 @@ def packed_linear_cached(weight):
     torch version counter: an optimizer step bumps it): inference re-uses one packing per layer
     instead of launching the pack kernel on every forward."""
     key = (weight.data_ptr(), weight._version, tuple(weight.shape), str(weight.device))
+    stream = torch.cuda.current_stream(weight.device)
     with _CACHE_LOCK:
         hit = _PACK_CACHE.get(key)
         if hit is not None:
             _PACK_CACHE.move_to_end(key)
-            return hit[0]
+    if hit is not None:
+        if hit[2] != stream.cuda_stream:  # packed on another stream: order this one behind the pack kernel
+            stream.wait_event(hit[3])
+        return hit[0]
     packed = pack_linear(weight)
+    with torch.cuda.device(weight.device):
+        ev = torch.cuda.Event()
+        ev.record(stream)
     with _CACHE_LOCK:
-        _PACK_CACHE[key] = (packed, weight)  # the weight stays alive: its address cannot be recycled under the key
+        # the weight stays alive: its address cannot be recycled under the key
+        _PACK_CACHE[key] = (packed, weight, stream.cuda_stream, ev)
         while len(_PACK_CACHE) > _PACK_CACHE_MAX:
             _PACK_CACHE.popitem(last=False)
     return packed

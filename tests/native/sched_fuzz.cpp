@@ -256,7 +256,7 @@ static void emulate_fused(const hg::FusedSched &f, int N, int M, const std::vect
   g_l1_fixups += f.n_fix_l1;
 }
 
-static void one_graph(std::mt19937 &rng, int N, int M, double mean, int hub_every, bool mega) {
+static void one_graph(std::mt19937 &rng, int N, int M, double mean, int hub_every, bool mega, bool dups) {
   std::vector<int32_t> ptr(1, 0), ind;
   std::geometric_distribution<int> size(1.0 / (mean + 1.0));
   std::uniform_int_distribution<int> vert(0, N - 1);
@@ -267,7 +267,10 @@ static void one_graph(std::mt19937 &rng, int N, int M, double mean, int hub_ever
     for (int k = 0; k < s; k++) {
       int v = mega && e == 0 ? k : vert(rng);
       if (hub_every && k == 0 && e % hub_every) v = 0;  // vertex 0 is a hub
-      if (!seen[v]) {
+      // repeated members stay in for about one draw in ten, and always for the forced hub: validate_csr and the
+      // MatrixMarket reader accept duplicate incidences, and every path must count them with multiplicity
+      const bool keep_dup = dups && (v == 0 || rng() % 10 == 0);
+      if (!seen[v] || keep_dup) {
         seen[v] = 1;
         ind.push_back(v);
       }
@@ -397,7 +400,7 @@ int main(int argc, char **argv) {
   balance_and_mtx(rng, argc > 1 ? argv[1] : "/tmp/sched_fuzz.mtx");
   for (int it = 0; it < 240; it++) {
     const int N = 1 + (int)(rng() % (it % 20 == 0 ? 4000 : 400)), M = (int)(rng() % (it % 20 == 0 ? 3000 : 300));
-    one_graph(rng, N, M, 0.5 + (it % 7) * 2.0, it % 3 == 0 ? 2 : 0, it % 11 == 5);
+    one_graph(rng, N, M, 0.5 + (it % 7) * 2.0, it % 3 == 0 ? 2 : 0, it % 11 == 5, it % 2 == 1 || it % 6 == 0);
   }
   // the random graphs must actually have reached the hub pass, hub parts, split rows and two-level fixups
   std::printf("hub schedules %ld, hub rounds %ld, heavy hubs %ld, extra hub parts %ld, split vertices %ld, first-level fixups %ld\n",
