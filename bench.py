@@ -15,10 +15,14 @@ The timed output is checked: after the timed region Y is compared with the CPU
 oracle on the same input (`parity`), and a mismatch makes the run fail -- the
 reference never times an unchecked variant either (TRY, hgnnAgg.cuh:1159-1169).
 
-`configs` (N = 1): the other BASELINE configurations measured the same way in
-the same run -- pubmed-shape x64 at F = 128 (config 3), the power-law
-|V|=1M |E|=4M hypergraph at F = 64 (config 4), and the weighted operator
-(degE, degV, W: HGNNConv itself) on the headline batch.
+`configs` (N = 1): measured the same way in the same run -- the other five cells
+of north_star's target matrix (cora / citeseer / pubmed shape x F = 32 / 128;
+pubmed-shape x64 at F = 128 is BASELINE config 3), config 3's MFMA path (the
+aggregation with the layer's 128 -> 128 linear folded in: hg_aggr_linear_f32,
+priced against the HBM and the fp32-MFMA roofline), the power-law |V|=1M |E|=4M
+hypergraph at F = 64 (config 4), and the weighted operator (degE, degV, W:
+HGNNConv itself) on the headline batch.  Every entry's output is checked against
+the oracle and against a float64 answer (scipy) at 1e-5 * max(1, |ref|).
 
 N > 1: one process per GPU (torchrun).  Headline: the batch sharded by hyperedge
 group = by hypergraph, K graphs per rank (weak scaling); no vertex is shared
@@ -80,6 +84,8 @@ def parse():
     p.add_argument("--sharded-edges", type=int, default=4_000_000)
     p.add_argument("--sharded-feat", type=int, default=64)
     p.add_argument("--sharded-chunks", type=int, default=2, help="column slices of the pipelined all-reduce")
+    p.add_argument("--force-collective", action="store_true",
+                   help="world size 1 under torchrun: initialise RCCL anyway and run the `sharded` section through it")
     p.add_argument("--share-gpu", action="store_true",
                    help="rehearse the N>1 path on one GPU: all ranks use cuda:0, gloo instead of RCCL")
     return p.parse_args()
@@ -188,6 +194,43 @@ def oracle_pass(base, inc, F, X_host, weighted, scales, time_it):
     return ref, Ns, cpu
 
 
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, exact f32, 64 FLOP/clk/SIMD
+
+
+def float64_answer(inc, X_host, scales, weight=None):
+    """Dv H De W H^T X in float64 (scipy CSR products): the answer both the kernels and the oracle's fp32
+    chains approximate.  With `weight` ([F_out, F_in]): (that) . weight^T."""
+    import numpy as np
+    import scipy.sparse as sp
+    HT = sp.csr_matrix((np.ones(inc.nnz, np.float64), inc.colind, inc.csrptr), shape=(inc.M, inc.N))
+    Xe = HT @ X_host.astype(np.float64)
+    if scales is not None:
+        degE, degV, W = scales
+        Xe *= degE.astype(np.float64)[:, None]
+        Xe *= W.astype(np.float64)[:, None]
+    Y = HT.T.tocsr() @ Xe
+    if scales is not None:
+        Y *= scales[1].astype(np.float64)[:, None]
+    if weight is not None:
+        Y = Y @ weight.astype(np.float64).T
+    return Y
+
+
+def float64_report(Y_dev, inc, X_host, scales, weight=None, scale_by_max=False):
+    """Every row of the timed output against the float64 answer at north_star's literal tolerance,
+    1e-5 * max(1, |ref|) -- no allowance for chain lengths.  scale_by_max (the linear epilogue):
+    1e-5 * max(1, max|ref|), errors of a K-term fp32 product chain being relative to the size of its
+    terms, not of a result that may have cancelled."""
+    import numpy as np
+    y64 = float64_answer(inc, X_host, scales, weight)
+    y = Y_dev.cpu().numpy().astype(np.float64)
+    den = np.maximum(1.0, np.abs(y64).max() if scale_by_max else np.abs(y64))
+    err = np.abs(y - y64) / den
+    return {"max_rel_err_vs_float64": float(err.max()), "float64_ok": bool(err.max() <= 1e-5),
+            "float64_rows_checked": int(inc.N),
+            "float64_bound": "1e-5*max(1,max|ref|)" if scale_by_max else "1e-5*max(1,|ref|)"}
+
+
 def parity_report(Y_dev, ref, nrows, inc):
     """Timed output vs the oracle.  Bound per row: 1e-5 * max(1, |ref|) (BASELINE.json north_star)
     plus the oracle's own worst-case rounding, u * (longest sequential chain feeding the row) --
@@ -210,9 +253,11 @@ def parity_report(Y_dev, ref, nrows, inc):
 
 
 def run_config(shape, replicas, F, weighted, variant, steps, warmup, dev, sync, barrier, rank, opts_kw,
-               want_cpu, want_parity):
+               want_cpu, want_parity, linear_out=0):
     """Build one workload on `dev`, time `steps` aggregations, check the output.  Returns
-    (result dict, state for the extras)."""
+    (result dict, cpu baseline dict, state for the extras).  linear_out > 0: the aggregation with the
+    layer's bias-free linear F -> linear_out folded in (hg_aggr_linear_f32; reference
+    model/ugsys/hgnn.py:22-23), the one MFMA contraction next to the path."""
     import numpy as np
     import torch
     import hypergef_amd as hg
@@ -241,11 +286,24 @@ def run_config(shape, replicas, F, weighted, variant, steps, warmup, dev, sync, 
         W = torch.ones(inc.M, device=dev)  # HGNNConv's Wdiag (model/ugsys/hgnn.py:12); random W: tests/test_gpu_parity.py
         scales_host = (degE.cpu().numpy(), degV.cpu().numpy(), W.cpu().numpy())
         n_w = 2
-    Y = torch.empty((inc.N, F), dtype=torch.float32, device=dev)
-    ws = torch.empty(max(plan.workspace_bytes(F), 256), dtype=torch.uint8, device=dev)
+    weight = weight_host = None
+    if linear_out:
+        from hypergef_amd import _lib
+        g = torch.Generator().manual_seed(7)
+        weight_host = (torch.randn(linear_out, F, generator=g) / F ** 0.5).numpy()
+        weight = torch.from_numpy(weight_host).to(dev)
+        packed = planmod.pack_linear(weight)
+        Y = torch.empty((inc.N, linear_out), dtype=torch.float32, device=dev)
+        ws = torch.empty(max(int(_lib.lib().hg_aggr_linear_workspace_bytes(plan._h, F)), 256), dtype=torch.uint8, device=dev)
 
-    def step():
-        plan.aggregate(ptr, ind, X, degE, degV, W, variant=variant, out=Y, workspace=ws)
+        def step():
+            plan.aggregate_linear(ptr, ind, X, weight, degE, degV, W, variant=variant, out=Y, workspace=ws, packed=packed)
+    else:
+        Y = torch.empty((inc.N, F), dtype=torch.float32, device=dev)
+        ws = torch.empty(max(plan.workspace_bytes(F), 256), dtype=torch.uint8, device=dev)
+
+        def step():
+            plan.aggregate(ptr, ind, X, degE, degV, W, variant=variant, out=Y, workspace=ws)
 
     for _ in range(warmup):
         step()
@@ -253,17 +311,22 @@ def run_config(shape, replicas, F, weighted, variant, steps, warmup, dev, sync, 
 
     launches = {"pull": 2, "fused": 1, "push_atomic": 1}[resolved]
     dominant = {"pull": "gather_rows_kernel (hop 1 + hop 2 launches averaged)",
-                "fused": "fused_packed_kernel", "push_atomic": "push_groups_kernel"}[resolved]
+                "fused": "fused_packed_kernel", "push_atomic": "push_tasks_kernel"}[resolved]
     info = fused_shape or {}
     helper_launches = 0
     if resolved == "fused":  # pre-pass / hub-pass / fixup launches of this schedule, timed inside the step
         helper_launches = int(info.get("n_mat", 0) > 0) + int(info.get("n_hub", 0) > 0) + int(info.get("fixups", 0) > 0)
     balg = b_alg(inc.N, inc.M, inc.nnz, F, n_w, degV is not None)
+    if linear_out:  # Y is [N, linear_out]; the packed weight is read once
+        balg += 4 * (inc.N * (linear_out - F) + linear_out * F)
+        dominant = "fused_packed_kernel<..., LIN = true> (hop 1, hop 2, rows . Wlin^T on v_mfma_f32_16x16x4_f32)"
     # the whole step's device time over its algorithmic bytes: helper launches count against the
     # step, so a schedule that needs them is not flattered
     step_s = dev_s / steps
     achieved = balg / step_s / 1e9
     name = workload_name(shape, replicas, F) + (", weighted (degE, degV, W)" if weighted else "")
+    if linear_out:
+        name += ", aggregation + linear %d->%d (hg_aggr_linear_f32)" % (F, linear_out)
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
@@ -273,7 +336,8 @@ def run_config(shape, replicas, F, weighted, variant, steps, warmup, dev, sync, 
         except Exception:
             traffic = None
     res = {
-        "workload": name, "op": "hgnnaggr (degE, degV, W)" if weighted else "H*H^T*X (aggr_proto)",
+        "workload": name, "op": ("(H*H^T*X) * Wlin^T (HGNNConv layer: aggregation + nn.Linear)" if linear_out else
+                                 "hgnnaggr (degE, degV, W)" if weighted else "H*H^T*X (aggr_proto)"),
         "vertices": inc.N, "hyperedges": inc.M, "nnz": inc.nnz, "feat_len": F,
         "variant": variant, "resolved_variant": resolved,
         "ms_per_step": wall / steps * 1e3, "device_ms_per_step": step_s * 1e3,
@@ -287,11 +351,36 @@ def run_config(shape, replicas, F, weighted, variant, steps, warmup, dev, sync, 
         "plan": {k: plan.info[k] for k in ("panels", "tasks", "fixups", "max_len", "short_max",
                                             "panel_rows", "panel_nnz")},
     }
+    if linear_out:
+        flops = 2.0 * inc.N * F * linear_out
+        res["roofline_mfma"] = {"bound": "mfma", "achieved": flops / step_s / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS,
+                                "unit": "TFLOP/s", "frac": flops / step_s / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                "dtype": "f32 (v_mfma_f32_16x16x4_f32: exact fp32 in, fp32 accumulate)",
+                                "flops_per_step": flops, "traffic": None,
+                                "time_at_peak_ms": flops / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3,
+                                "time_at_hbm_peak_ms": balg / (HBM_PEAK_GBS * 1e9) * 1e3}
     cpu = None
     if rank == 0 and (want_cpu or want_parity):
-        ref, nrows, cpu = oracle_pass(base, inc, F, X_host, weighted, scales_host, want_cpu)
+        if linear_out:
+            # the reference's order: project (float64 product rounded once to fp32), then the oracle's aggregation
+            import numpy as np
+            Z = (X_host.astype(np.float64) @ weight_host.T.astype(np.float64)).astype(np.float32)
+            ref, nrows, cpu = oracle_pass(base, inc, linear_out, Z, weighted, scales_host, False)
+            y = Y[:nrows].cpu().numpy()
+            scale = max(1.0, float(np.abs(ref).max()))
+            err = float(np.abs(y - ref).max() / scale)
+            res["parity"] = {"ok": bool(err <= 2e-5), "bit_exact": False, "max_rel_err": err, "rows_checked": int(nrows),
+                             "rows_total": int(inc.N), "bound": "2e-5*max(1,max|ref|): (A X) W^T against A (X W^T), the same "
+                             "fp32 fma chains in another order (tests/test_gpu_parity.py::_assert_close_linear)",
+                             "against": "oracle aggregation of the projected rows (linear-then-aggregate, the reference's order)"}
+        else:
+            ref, nrows, cpu = oracle_pass(base, inc, F, X_host, weighted, scales_host, want_cpu)
+            if want_parity:
+                res["parity"] = parity_report(Y, ref, nrows, inc)
         if want_parity:
-            res["parity"] = parity_report(Y, ref, nrows, inc)
+            f64 = float64_report(Y, inc, X_host, scales_host, weight_host, scale_by_max=bool(linear_out))
+            res["parity"].update(f64)
+            res["parity"]["ok"] = bool(res["parity"]["ok"] and f64["float64_ok"])
     state = dict(base=base, inc=inc, plan=plan, ptr=ptr, ind=ind, X=X, Y=Y, ws=ws, opts=opts,
                  degE=degE, degV=degV, W=W, wall=wall)
     return res, cpu, state
@@ -370,9 +459,10 @@ def sharded_section(args, dev, sync, barrier, rank, world):
     for exchange in ("allreduce", "reduce_scatter", "allreduce_pipelined"):
         try:
             if exchange == "allreduce_pipelined":  # SURVEY 8(e) iv: column slices, collective c overlaps kernels c + 1
-                agg = ShardedAggregator(inc, device=dev, exchange="allreduce", column_chunks=args.sharded_chunks)
+                agg = ShardedAggregator(inc, device=dev, exchange="allreduce", column_chunks=args.sharded_chunks,
+                                        force_collective=args.force_collective)
             else:
-                agg = ShardedAggregator(inc, device=dev, exchange=exchange)
+                agg = ShardedAggregator(inc, device=dev, exchange=exchange, force_collective=args.force_collective)
             for _ in range(3):
                 Y = agg.aggregate(X)
             w, _ = timed_steps(lambda: agg.aggregate(X), n, sync, barrier)
@@ -437,8 +527,11 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.share_gpu:
             dist.init_process_group("gloo")
         else:
@@ -503,19 +596,24 @@ def main():
     del st
     torch.cuda.empty_cache()
 
-    if world > 1 and not args.no_extras:
+    if (world > 1 or args.force_collective) and not args.no_extras:
         out["sharded"] = sharded_section(args, dev, sync, barrier, rank, world)
 
     if one and not args.no_configs and not args.no_extras:
         # the other BASELINE configurations, same measurement, bounded step counts
         configs = []
-        todo = [("pubmed", 64, 128, False), ("powerlaw", 1, 64, False), (args.shape, args.replicas, F, True)]
-        for shape, reps, feat, weighted in todo:
-            if (shape, reps, feat, weighted) == (args.shape, args.replicas, F, args.weighted):
+        # north_star's target matrix (the headline is its cora F = 32 cell; replica counts put X + Y beyond the 256 MiB
+        # Infinity Cache), config 3 and its MFMA path, config 4, the weighted operator
+        todo = [("citeseer", 1024, 32, False, 0), ("pubmed", 256, 32, False, 0), ("cora", 256, 128, False, 0),
+                ("citeseer", 256, 128, False, 0), ("pubmed", 64, 128, False, 0), ("pubmed", 64, 128, False, 128),
+                ("powerlaw", 1, 64, False, 0), (args.shape, args.replicas, F, True, 0)]
+        for shape, reps, feat, weighted, lin in todo:
+            if (shape, reps, feat, weighted, lin) == (args.shape, args.replicas, F, args.weighted, 0):
                 continue
             try:
                 r, c, s2 = run_config(shape, reps, feat, weighted, "auto", args.config_steps, 10, dev, sync, barrier,
-                                      rank, dict(xcd_remap=True), want_cpu=False, want_parity=not args.no_parity)
+                                      rank, dict(xcd_remap=True), want_cpu=False, want_parity=not args.no_parity,
+                                      linear_out=lin)
                 del s2
                 torch.cuda.empty_cache()
                 for k in ("plan", "plan_build_s"):
@@ -529,7 +627,7 @@ def main():
     if rank == 0:
         out["cpu_baseline"] = cpu if one and not args.no_cpu_baseline else None
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or args.force_collective:
         dist.barrier()
         dist.destroy_process_group()
     if failed:

@@ -363,8 +363,9 @@ int pick_variant_uncached(const hg_plan *plan, int32_t F, bool vec4, int32_t *va
 int run_sched(const hg_plan *p, const hg::Sched &s, int32_t F, const int32_t *ptr,
               const int32_t *ind, const float *src, const float *scaleA, const float *scaleB,
               const int32_t *scale_map, const int32_t *dst_map, float *dst, float *partial,
-              hipStream_t stream) {
+              hipStream_t stream, bool nt_dst = false) {
   hg::GatherArgs a;
+  a.nt_dst = nt_dst ? 1 : 0;
   a.scale_map = scale_map;
   a.dst_map = dst_map;
   a.ptr = ptr;
@@ -454,18 +455,19 @@ int run_hop(const hg_plan *p, int hop, int32_t F, const int32_t *ptr, const int3
     sa.partial = partial;
     sa.F = F;
     sa.xcd_remap = (p->opts.flags & HG_PLAN_NO_XCD_REMAP) ? 0 : 1;
+    sa.nt_dst = hop == 1;  // hop 2 writes Y; hop 1's Xe is read straight back
     if (sa.nrec == 0) return HG_OK;
     if (hg::stream_rows_ok(sa, true)) {
       hipError_t e = hg::launch_stream_rows(sa, stream);
       if (e == hipSuccess)
         e = hg::launch_fixups(rs->d_fixups, (int)rs->fixups.size(), rs->n_fix_l1, F, partial, dst, scaleA, scaleB,
-                              nullptr, true, stream);
+                              nullptr, true, stream, hop == 1);
       if (e != hipSuccess) return hip_fail("stream_rows launch", e);
       return HG_OK;
     }
   }
   return run_sched(p, p->sched[hop], F, ptr, ind, src, scaleA, scaleB, nullptr, nullptr, dst, partial,
-                   stream);
+                   stream, hop == 1);
 }
 
 // pull_only: the call runs the pull layout whatever schedules exist (a forced HG_VARIANT_PULL, a single hop): a
@@ -1034,7 +1036,7 @@ static int aggr_impl(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
     if (e != hipSuccess) return hip_fail("fused_panel launch", e);
     // (d) hubs and split vertices: Y[v] = degV[v] * (sum of the vertex's partial rows), fixed order
     if (!f->fixups.empty()) {
-      e = hg::launch_fixups(f->d_fixups, (int)f->fixups.size(), f->n_fix_l1, F, partial, Y, degV, nullptr, nullptr, vec4, s);
+      e = hg::launch_fixups(f->d_fixups, (int)f->fixups.size(), f->n_fix_l1, F, partial, Y, degV, nullptr, nullptr, vec4, s, true);
       if (e != hipSuccess) return hip_fail("fixup launch", e);
     }
     return HG_OK;

@@ -24,6 +24,7 @@ struct GatherArgs {
   int32_t F;
   int32_t panel_rows, panel_nnz;  // LDS carve-up
   int32_t xcd_remap;
+  int32_t nt_dst = 0;  // rows of dst are final output nothing reads again in this call chain: streaming (nt) stores
 };
 
 // What happens to an aggregated row t = Aggr(X)[v] on its way through the linear epilogue:
@@ -100,6 +101,7 @@ struct StreamArgs {
   const float *scaleA, *scaleB; // indexed by the record's sidx lists, or null
   float *dst, *partial;
   int32_t F, xcd_remap;
+  int32_t nt_dst = 0;  // as GatherArgs::nt_dst
 };
 
 struct PushArgs {
@@ -119,7 +121,7 @@ size_t hub_pass_lds_bytes(int32_t cap, int32_t row_floats, int32_t max_rec_words
 // Y[fx.row] = scale[fx.row] * (sum of the fixup's partial rows); first-level fixups first
 hipError_t launch_fixups(const Fixup *fixups, int nfix, int nfix_l1, int32_t F, float *partial, float *Y,
                          const float *scaleA, const float *scaleB, const int32_t *scale_map, bool vec4,
-                         hipStream_t stream);
+                         hipStream_t stream, bool nt_dst = false);
 bool stream_rows_ok(const StreamArgs &a, bool vec4);  // buffer-addressable table, 16-byte lanes
 hipError_t launch_stream_rows(const StreamArgs &a, hipStream_t stream);
 bool fused_linear_ok(const FusedArgs &a);  // can launch_fused run this call's linear epilogue?

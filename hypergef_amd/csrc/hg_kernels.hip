@@ -22,6 +22,19 @@ namespace hg {
 #ifndef HG_ROWS_WAVES
 #define HG_ROWS_WAVES 7
 #endif
+// Rows of Y leave the panel kernel with the streaming (nt) hint.  Same-box A/B, round 3 (tools/nt_probe.sh, then
+// tools/ab_lib.sh against a -DHG_Y_NT=0 build): see profiles/r03_experiments.md.
+#ifndef HG_Y_NT
+#define HG_Y_NT 1
+#endif
+// Panel records are read once per launch: HG_REC_NT = 1 copies them with the streaming hint as well.
+#ifndef HG_REC_NT
+#define HG_REC_NT 0
+#endif
+// HG_X_NT = 1: the panel kernel's gathers of X rows carry the streaming hint too (experiment).
+#ifndef HG_X_NT
+#define HG_X_NT 0
+#endif
 template <int VEC> struct Vec;
 template <> struct Vec<1> {
   float x;
@@ -30,10 +43,14 @@ template <> struct Vec<1> {
   __device__ __forceinline__ static Vec load_buf(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return Vec{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0))};
   }
+  __device__ __forceinline__ static Vec load_buf_nt(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return Vec{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 2))};
+  }
   __device__ __forceinline__ static Vec loadu(const float *p) { return Vec{*p}; }
   __device__ __forceinline__ void store(float *p) const { *p = x; }
   __device__ __forceinline__ void store_n(float *p, int) const { *p = x; }
   __device__ __forceinline__ void store_nt(float *p) const { __builtin_nontemporal_store(x, p); }
+  __device__ __forceinline__ void store_n_nt(float *p, int) const { __builtin_nontemporal_store(x, p); }
   __device__ __forceinline__ void add(const Vec &o) { x += o.x; }
   __device__ __forceinline__ void mul(float s) { x *= s; }
   __device__ __forceinline__ void xor_reduce(int off) { x += __shfl_xor(x, off, 64); }
@@ -47,6 +64,10 @@ template <> struct Vec<4> {
   __device__ __forceinline__ static Vec load_buf(__amdgpu_buffer_rsrc_t r, unsigned off) {
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
     return Vec{__builtin_bit_cast(float4, (u4)__builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0))};
+  }
+  __device__ __forceinline__ static Vec load_buf_nt(__amdgpu_buffer_rsrc_t r, unsigned off) {  // cache policy bit 1 = nt
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    return Vec{__builtin_bit_cast(float4, (u4)__builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 2))};
   }
   __device__ __forceinline__ void store(float *p) const { *reinterpret_cast<float4 *>(p) = v; }
   // Rows whose width is not a multiple of four floats (or whose base is only 4-byte aligned) still move as
@@ -70,6 +91,16 @@ template <> struct Vec<4> {
   __device__ __forceinline__ void store_nt(float *p) const {
     typedef float f4 __attribute__((ext_vector_type(4)));
     __builtin_nontemporal_store(f4{v.x, v.y, v.z, v.w}, reinterpret_cast<f4 *>(p));
+  }
+  // store_n with the streaming hint (global_store_dwordx4 ... nt): rows of Y, which nothing reads again in this launch
+  __device__ __forceinline__ void store_n_nt(float *p, int n) const {
+    if (n >= 4) {
+      __builtin_nontemporal_store(f4u{v.x, v.y, v.z, v.w}, reinterpret_cast<f4u *>(p));
+    } else {
+      __builtin_nontemporal_store(v.x, p);
+      if (n > 1) __builtin_nontemporal_store(v.y, p + 1);
+      if (n > 2) __builtin_nontemporal_store(v.z, p + 2);
+    }
   }
   __device__ __forceinline__ void add(const Vec &o) {
     v.x += o.v.x; v.y += o.v.y; v.z += o.v.z; v.w += o.v.w;
@@ -130,7 +161,8 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const GatherArgs a) {
         const int64_t drow = a.dst_map ? a.dst_map[tk.row] : tk.row;
         if (a.scaleA) acc.mul(a.scaleA[srow]);
         if (a.scaleB) acc.mul(a.scaleB[srow]);
-        acc.store(a.dst + drow * F + col);
+        if (HG_Y_NT && a.nt_dst) acc.store_n_nt(a.dst + drow * F + col, VEC);
+        else acc.store(a.dst + drow * F + col);
       } else {
         acc.store(a.partial + (int64_t)tk.slot * F + col);
       }
@@ -175,7 +207,10 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const GatherArgs a) {
       if (a.scaleB) acc.mul(sB[row]);
     }
     const int64_t drow = a.dst_map ? sdst[row] : pn.row0 + row;
-    if (col_ok) acc.store(a.dst + drow * F + col);
+    if (col_ok) {
+      if (HG_Y_NT && a.nt_dst) acc.store_n_nt(a.dst + drow * F + col, VEC);
+      else acc.store(a.dst + drow * F + col);
+    }
   };
 
   int pos = sptr[r];
@@ -269,7 +304,8 @@ __global__ __launch_bounds__(256) void fixup_rows_kernel(const GatherArgs a, con
   const int64_t drow = a.dst_map ? a.dst_map[fx.row] : fx.row;
   if (a.scaleA) acc.mul(a.scaleA[srow]);
   if (a.scaleB) acc.mul(a.scaleB[srow]);
-  acc.store_n(a.dst + drow * F + col, a.F - col);
+  if (HG_Y_NT && a.nt_dst) acc.store_n_nt(a.dst + drow * F + col, a.F - col);
+  else acc.store_n(a.dst + drow * F + col, a.F - col);
 }
 
 // Diagnostic stamps: lane 0 of every wave adds the ticks since the previous stamp to a
@@ -467,7 +503,8 @@ __device__ __forceinline__ void panel_times_wt_staged(float *t, int nrows, int F
     const int64_t yrow = rowmap ? (int64_t)rowmap[r] : row0 + r;
     float4 o = *reinterpret_cast<const float4 *>(t + r * LD + c);
     if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
-    *reinterpret_cast<float4 *>(Y + yrow * F_out + c) = o;
+    if (HG_Y_NT) Vec<4>{o}.store_nt(Y + yrow * F_out + c);
+    else *reinterpret_cast<float4 *>(Y + yrow * F_out + c) = o;
   }
 }
 
@@ -710,7 +747,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LIN ? (LPR 
 
   // records are padded to whole 16-byte units: one dwordx4 per lane copies 4 KB per pass
   for (int i = tid; i < (rt.len >> 2); i += BS)
-    reinterpret_cast<hg_i4 *>(rec)[i] = reinterpret_cast<const hg_i4 *>(grec)[i];
+    reinterpret_cast<hg_i4 *>(rec)[i] = HG_REC_NT ? __builtin_nontemporal_load(reinterpret_cast<const hg_i4 *>(grec) + i)
+                                                  : reinterpret_cast<const hg_i4 *>(grec)[i];
   // The scale gathers start from the ids in global memory, in the same round trip as the
   // record copy (the descriptor says where they are), not after it.
   if (a.degE || a.W)
@@ -781,7 +819,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LIN ? (LPR 
         }
         if constexpr (FAST) {
           const unsigned off = __umul24((unsigned)ent[j], row_bytes) + col_off;  // flags sit above bit 23
-          v[j] = V::load_buf(MATPH ? rm : rx, off);
+          v[j] = (HG_X_NT && !MATPH) ? V::load_buf_nt(rx, off) : V::load_buf(MATPH ? rm : rx, off);
         } else {
           const bool on = col_ok && ent[j] != idle && !(DBG && (a.debug & 1));
           const int64_t idx = ent[j] & 0x3fffffff;
@@ -882,6 +920,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LIN ? (LPR 
         const int pr = prow[r];  // vertex id, or bit 31 | partial row (a piece of a split vertex)
         float *dst = (pr < 0 ? a.partial + (int64_t)(pr & 0x7fffffff) * F : a.Y + (int64_t)pr * F) + col;
         if (DBG && (a.debug & 64)) acc.store_nt(dst);
+        else if (HG_Y_NT && pr >= 0) acc.store_n_nt(dst, a.F - col);  // partial rows are read back by the fixup pass: plain
         else acc.store_n(dst, a.F - col);
       }
     }
@@ -1177,7 +1216,10 @@ __global__ __launch_bounds__(256) void stream_rows_kernel(const StreamArgs a) {
         if (a.scaleB) acc.mul(sB[slot]);
         const int d = dstl[slot];
         slot++;
-        if (col_ok) acc.store_n((d < 0 ? a.partial + (int64_t)(d & 0x7fffffff) * F : a.dst + (int64_t)d * F) + col, a.F - col);
+        if (col_ok) {
+          if (HG_Y_NT && a.nt_dst && d >= 0) acc.store_n_nt(a.dst + (int64_t)d * F + col, a.F - col);
+          else acc.store_n((d < 0 ? a.partial + (int64_t)(d & 0x7fffffff) * F : a.dst + (int64_t)d * F) + col, a.F - col);
+        }
         acc = V::zero();
       }
     }
@@ -1187,40 +1229,63 @@ __global__ __launch_bounds__(256) void stream_rows_kernel(const StreamArgs a) {
   if (s0 < steps) block(s0, std::false_type{});
 }
 
-// The reference's register-fused scheme on wave64: LPR lanes = LPR feature
-// columns of one task, 64/LPR tasks per wave.  Gather-sum the read partition,
-// scale by degE*W, scatter acc*degV[v] to the write partition with hardware
-// fp32 atomics (global_atomic_add_f32, one contiguous LPR*4-byte segment per
-// destination row).
-template <int LPR>
-__global__ __launch_bounds__(256) void push_groups_kernel(const PushArgs a) {
-  const int tid = threadIdx.x;
-  const int64_t gid = (int64_t)blockIdx.x * (256 / LPR) + tid / LPR;
-  const int k = blockIdx.y * LPR + (tid & (LPR - 1));
-  if (gid >= a.n_group || k >= a.F) return;
+// Push form (the scheme the reference's group_* tensors describe, HyperGsys/balancer.py:15-33): a task sums the
+// member rows of one partition of a hyperedge and adds the scaled sum into the rows of Y that another partition
+// names, with memory-side fp32 atomics.  Here in this backend's lane layout: a row is spread over LPR lanes of VEC
+// floats (16-byte gathers where the width allows), a wave carries 64/LPR tasks, the source rows go eight at a time
+// into flight, and the scatter issues one global_atomic_add_f32 per float of the lane's piece.  Kept as the
+// drop-in for callers that bring the reference's schedule (any ngs, the w^2 task grid included) and as the CLI's
+// comparator; AUTO never picks it -- atomics run at about 1.3 TB/s of added bytes on this chip.
+template <int LPR, int VEC>
+__global__ __launch_bounds__(256) void push_tasks_kernel(const PushArgs a) {
+  using V = Vec<VEC>;
+  constexpr int TPB = 256 / LPR, U = 8;
+  const int lane = threadIdx.x & (LPR - 1);
+  const int64_t task = (int64_t)blockIdx.x * TPB + threadIdx.x / LPR;
+  const int col = (blockIdx.y * LPR + lane) * VEC;
+  if (task >= a.n_group || col >= a.F) return;
   const int64_t F = a.F;
-  int eid, rd_start, rd_end, wr_start, wr_end;
+  // source partition, destination partition and hyperedge of this task: from the caller's schedule, or one task
+  // per hyperedge covering all its members
+  int e, src_lo, src_hi, dst_lo, dst_hi;
   if (a.group_key) {
-    eid = a.group_row[gid];
-    const int rid = a.group_st[gid], wid = a.group_ed[gid];
-    rd_start = a.group_key[rid];
-    rd_end = a.group_key[rid + 1];
-    wr_start = a.group_key[wid];
-    wr_end = a.group_key[wid + 1];
+    e = a.group_row[task];
+    const int ps = a.group_st[task], pd = a.group_ed[task];
+    src_lo = a.group_key[ps];
+    src_hi = a.group_key[ps + 1];
+    dst_lo = a.group_key[pd];
+    dst_hi = a.group_key[pd + 1];
   } else {
-    eid = (int)gid;
-    rd_start = wr_start = a.csrptr_t[eid];
-    rd_end = wr_end = a.csrptr_t[eid + 1];
+    e = (int)task;
+    src_lo = dst_lo = a.csrptr_t[e];
+    src_hi = dst_hi = a.csrptr_t[e + 1];
   }
-  float acc = 0.f;
-  for (int p = rd_start; p < rd_end; p++) acc += a.X[(int64_t)a.colind_t[p] * F + k];
-  const float degE_val = a.degE ? a.degE[eid] : 1.f;
-  const float W_val = a.W ? a.W[eid] : 1.f;
-  acc *= degE_val * W_val;
-  for (int p = wr_start; p < wr_end; p++) {
+  const float *xcol = a.X + col;
+  V sum = V::zero();
+  for (int p = src_lo; p < src_hi; p += U) {  // members in order: the sum is the reference kernel's, bit for bit
+    V v[U];
+#pragma unroll
+    for (int j = 0; j < U; j++) {
+      const int q = min(p + j, src_hi - 1);
+      v[j] = V::loadu(xcol + (int64_t)a.colind_t[q] * F);
+    }
+#pragma unroll
+    for (int j = 0; j < U; j++)
+      if (p + j < src_hi) sum.add(v[j]);
+  }
+  float es = a.degE ? a.degE[e] : 1.f;  // degE * W first, then the sum times that product (hgnnaggr_cuda.cu:38)
+  es *= a.W ? a.W[e] : 1.f;
+  sum.mul(es);
+  const int n = min(VEC, a.F - col);  // floats of this lane that exist
+  for (int p = dst_lo; p < dst_hi; p++) {
     const int64_t v = a.colind_t[p];
-    const float degV_val = a.degV ? a.degV[v] : 1.f;
-    atomicAdd(a.Y + v * F + k, acc * degV_val);
+    V out = sum;
+    if (a.degV) out.mul(a.degV[v]);
+    float *y = a.Y + v * F + col;
+    const float *o = reinterpret_cast<const float *>(&out);
+#pragma unroll
+    for (int j = 0; j < VEC; j++)
+      if (j < n) atomicAdd(y + j, o[j]);
   }
 }
 
@@ -1342,9 +1407,10 @@ hipError_t launch_gather(const GatherArgs &a, int nfix, int nfix_l1, const Fixup
 
 hipError_t launch_fixups(const Fixup *fixups, int nfix, int nfix_l1, int32_t F, float *partial, float *Y,
                          const float *scaleA, const float *scaleB, const int32_t *scale_map, bool vec4,
-                         hipStream_t stream) {
+                         hipStream_t stream, bool nt_dst) {
   if (nfix == 0) return hipSuccess;
   GatherArgs a{};
+  a.nt_dst = nt_dst ? 1 : 0;
   a.F = F;
   a.partial = partial;
   a.dst = Y;
@@ -1633,16 +1699,19 @@ int fused_tile_row_floats(int F, bool vec4) {
 }
 
 hipError_t launch_push(const PushArgs &a, hipStream_t stream) {
-  const int lpr = std::min(64, next_pow2(std::max(a.F, 1)));
+  const bool vec4 = a.F % 4 == 0;  // dword-aligned 16-byte gathers (loadu: X may be only 4-byte aligned); other widths one float per lane
+  const int lanes = vec4 ? a.F / 4 : a.F;
+  const int lpr = std::min(64, next_pow2(std::max(lanes, 1)));
   const int per_block = 256 / lpr;
-  const int col_tiles = (a.F + lpr - 1) / lpr;
+  const int tw = lpr * (vec4 ? 4 : 1);
+  const int col_tiles = (a.F + tw - 1) / tw;
   const int64_t nblocks = (a.n_group + per_block - 1) / per_block;
   if (nblocks == 0) return hipSuccess;
   if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
-#define HG_CASE(L)                                                                               \
-  case L:                                                                                        \
-    hipLaunchKernelGGL((push_groups_kernel<L>), dim3((unsigned)nblocks, col_tiles), dim3(256), 0, \
-                       stream, a);                                                               \
+#define HG_CASE(L)                                                                                              \
+  case L:                                                                                                       \
+    if (vec4) hipLaunchKernelGGL((push_tasks_kernel<L, 4>), dim3((unsigned)nblocks, col_tiles), dim3(256), 0, stream, a); \
+    else hipLaunchKernelGGL((push_tasks_kernel<L, 1>), dim3((unsigned)nblocks, col_tiles), dim3(256), 0, stream, a);      \
     break;
   switch (lpr) {
     HG_CASE(1)

@@ -62,9 +62,13 @@ class ShardedAggregator:
     and the collective over gloo without a GPU."""
 
     def __init__(self, inc, rank=None, world=None, device=None, local_op=None, exchange="allreduce",
-                 column_chunks=1):
+                 column_chunks=1, force_collective=False):
         self.rank = dist.get_rank() if rank is None else rank
         self.world = dist.get_world_size() if world is None else world
+        # A world of one needs no exchange and skips it.  force_collective=True issues the collectives anyway
+        # (a one-rank communicator): the RCCL code path of this class -- all-reduce, padded reduce-scatter, the
+        # asynchronous pipelined form -- can then be executed and checked on a single GPU.
+        self._collective = self.world > 1 or bool(force_collective)
         self.parts = partition_hyperedges(inc.csrptr, self.world)
         self.lo, self.hi = self.parts[self.rank]
         self.local = local_incidence(inc, self.lo, self.hi)
@@ -94,10 +98,10 @@ class ShardedAggregator:
 
     def aggregate(self, X, degE=None, degV=None, W=None):
         dE, dV, dW = self.slice_edge_vector(degE), None if degV is None else degV.reshape(-1), self.slice_edge_vector(W)
-        if self.column_chunks > 1 and self.world > 1 and self.exchange != "none":
+        if self.column_chunks > 1 and self._collective and self.exchange != "none":
             return self._aggregate_pipelined(X, dE, dV, dW)
         Y = self._local_op(self.local, X, dE, dV, dW)
-        if self.exchange == "allreduce" and self.world > 1:
+        if self.exchange == "allreduce" and self._collective:
             dist.all_reduce(Y, op=dist.ReduceOp.SUM)
         elif self.exchange == "reduce_scatter":
             return self._reduce_scatter(Y)
@@ -146,7 +150,7 @@ class ShardedAggregator:
 
     def apply(self, X, degE=None, degV=None, W=None):
         """`aggregate` as an autograd node (training): gradient for X only, as the reference's
-        operators (hgnnaggr.cc:51-64).  Backward follows ops.set_backward: "reference" = the
+        operators (hgnnaggr.cc:51-64).  Backward follows the calling thread's ops.Options.backward: "reference" = the
         forward operator on grad_out, "adjoint" = H diag(degE W) H^T diag(degV) grad; either way
         each rank applies its shard's operator to the (replicated) grad_out and the partial
         gradients are summed by the same collective, because X is replicated.  Needs a full Y
@@ -164,7 +168,7 @@ class ShardedAggregator:
 
     def _reduce_scatter(self, Y):
         lo, hi = self.row_range()
-        if self.world == 1:
+        if not self._collective:
             return Y
         blk = -(-self.N // self.world)
         F = Y.shape[1]
@@ -181,7 +185,9 @@ class ShardedAggregator:
 class _ShardedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, agg, X, degE, degV, W):
+        from . import ops
         ctx.agg = agg
+        ctx.backward_mode = ops.current_options().backward  # the forward's options, whichever thread runs the backward
         ctx.save_for_backward(degE, degV, W)
         return agg.aggregate(X, degE, degV, W)
 
@@ -190,7 +196,7 @@ class _ShardedFn(torch.autograd.Function):
         from . import ops
         degE, degV, W = ctx.saved_tensors
         g = grad_out.contiguous()
-        if ops._STATE["backward"] == "reference" or degV is None:
+        if ctx.backward_mode == "reference" or degV is None:
             gx = ctx.agg.aggregate(g, degE, degV, W)
         else:
             gx = ctx.agg.aggregate(g * degV.reshape(-1, 1), degE, None, W)
@@ -203,9 +209,10 @@ class ColumnShardedAggregator:
     `sliced=True`) and returns Y[:, columns(rank)].  The narrower rows cost coalescing (F = 64 over 8 ranks is
     32-byte rows); `gather=True` all-gathers the blocks into the full Y on every rank."""
 
-    def __init__(self, inc, rank=None, world=None, device=None, local_op=None):
+    def __init__(self, inc, rank=None, world=None, device=None, local_op=None, force_collective=False):
         self.rank = dist.get_rank() if rank is None else rank
         self.world = dist.get_world_size() if world is None else world
+        self._collective = self.world > 1 or bool(force_collective)  # as ShardedAggregator
         self.inc = inc
         self.N, self.M = inc.N, inc.M
         self.device = device
@@ -236,7 +243,7 @@ class ColumnShardedAggregator:
             Yr = self._local_op(self.inc, Xr, flat(degE), flat(degV), flat(W))
         else:
             Yr = X.new_empty((self.N, 0))
-        if not gather or self.world == 1:
+        if not gather or not self._collective:
             return Yr
         blk = -(-F // self.world)
         mine = Yr if Yr.shape[1] == blk else torch.cat([Yr, Yr.new_zeros((self.N, blk - Yr.shape[1]))], dim=1)

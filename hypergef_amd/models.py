@@ -23,9 +23,16 @@ from .ops import HGNNAggr, HGNNAggrLinear, UniGNNConv, UniGNNConvdeg
 
 # ---- hgsys convolutions (model/ugsys/*.py) -----------------------------------
 
+def _variant_of(options):
+    return (options or ops.current_options()).variant
+
+
 class HyperGsysHGNN(nn.Module):
-    def __init__(self, hyperg, in_channels, out_channels, first_aggr, heads=1):
+    # `options` (an ops.Options, or None = the caller's current options at every forward) is this backend's
+    # addition to the reference's constructor arguments: per-model kernel family / backward rule / linear folding
+    def __init__(self, hyperg, in_channels, out_channels, first_aggr, heads=1, options=None):
         super().__init__()
+        self.options = options
         self.W = ops.Linear(in_channels, heads * out_channels, bias=False)
         self.Wdiag = torch.ones(hyperg.degE.shape[0]).to(hyperg.device)
         self.heads, self.in_channels, self.out_channels = heads, in_channels, out_channels
@@ -33,23 +40,24 @@ class HyperGsysHGNN(nn.Module):
         self.first_aggr = first_aggr
 
     def forward(self, X):
-        if ops._STATE["variant"] in ("auto", "pull", "fused"):
-            # same operator, one pass where that is faster (ops.set_fuse_linear; two-step otherwise)
-            return HGNNAggrLinear(self.hyperg, X, self.W.weight, self.degE, self.degV, self.Wdiag)
+        if _variant_of(self.options) in ("auto", "pull", "fused"):
+            # same operator, one pass where that is faster (Options.fuse_linear; two-step otherwise)
+            return HGNNAggrLinear(self.hyperg, X, self.W.weight, self.degE, self.degV, self.Wdiag, options=self.options)
         X = self.W(X)
-        return HGNNAggr(self.hyperg, X, self.degE, self.degV, self.Wdiag, self.first_aggr)
+        return HGNNAggr(self.hyperg, X, self.degE, self.degV, self.Wdiag, self.first_aggr, options=self.options)
 
 
 class HyperGsysUinGINConv(nn.Module):
-    def __init__(self, hyperg, in_channels, out_channels, first_aggr, heads=1):
+    def __init__(self, hyperg, in_channels, out_channels, first_aggr, heads=1, options=None):
         super().__init__()
+        self.options = options
         self.W = ops.Linear(in_channels, heads * out_channels, bias=False)
         self.heads, self.in_channels, self.out_channels = heads, in_channels, out_channels
         self.hyperg, self.degE, self.degV = hyperg, hyperg.degE, hyperg.degV
         self.eps = nn.parameter.Parameter(torch.FloatTensor([0]))
 
     def forward(self, X):
-        if ops._STATE["variant"] in ("auto", "pull", "fused") and ops.linear_fusion_pays(X.shape[1], self.W.weight.shape[0]):
+        if _variant_of(self.options) in ("auto", "pull", "fused") and ops.linear_fusion_pays(X.shape[1], self.W.weight.shape[0]):
             # (1 + eps) W(X) + Aggr(W(X)) = ((1 + eps) X + Aggr(X)) . W^T: the whole layer in one pass
             # training: cb stays a tensor (eps is learned: its gradient flows through cb, and reading the value
             # costs one device-to-host copy per step); without grad the value is read once per eps update and
@@ -62,22 +70,23 @@ class HyperGsysUinGINConv(nn.Module):
                     self._eps_host = (key, float(self.eps.detach()))
                 cb = 1.0 + self._eps_host[1]
             return ops.aggr_res_linear(self.hyperg.H_T_csrptr, self.hyperg.H_T_colind, X, self.W.weight,
-                                       residual=X, ca=1.0, cb=cb)
+                                       residual=X, ca=1.0, cb=cb, options=self.options)
         X = self.W(X)
-        Xv = UniGNNConv(self.hyperg, X)
+        Xv = UniGNNConv(self.hyperg, X, options=self.options)
         return (1 + self.eps) * X + Xv
 
 
 class HyperGsysUniGCNII(nn.Module):
-    def __init__(self, hyperg, in_channels, out_channels, heads=1):
+    def __init__(self, hyperg, in_channels, out_channels, heads=1, options=None):
         super().__init__()
+        self.options = options
         self.W = ops.Linear(in_channels, out_channels, bias=False)
         self.heads, self.in_channels, self.out_channels = heads, in_channels, out_channels
         self.hyperg, self.degE, self.degV = hyperg, hyperg.degE, hyperg.degV
 
     def forward(self, X, X0, alpha, beta, relu=False):
         F = X.shape[1]
-        if ops._STATE["variant"] in ("auto", "pull", "fused") and ops.linear_fusion_pays(F, self.W.weight.shape[0]) \
+        if _variant_of(self.options) in ("auto", "pull", "fused") and ops.linear_fusion_pays(F, self.W.weight.shape[0]) \
                 and self.W.weight.shape[0] == F:
             # Xi = (1 - alpha) Xv + alpha X0;  (1 - beta) Xi + beta W(Xi) = Xi . ((1 - beta) I + beta W)^T:
             # aggregation, both mixes, the projection and the model's relu in one pass
@@ -85,8 +94,9 @@ class HyperGsysUniGCNII(nn.Module):
                 self._eye = torch.eye(F, device=X.device, dtype=X.dtype)
             M = torch.lerp(self._eye, self.W.weight, float(beta))  # (1 - beta) I + beta W, one kernel
             return ops.aggr_res_linear(self.hyperg.H_T_csrptr, self.hyperg.H_T_colind, X, M, residual=X0,
-                                       ca=1 - alpha, cb=alpha, degE=self.degE, degV=self.degV, relu=relu)
-        Xv = UniGNNConvdeg(self.hyperg, X, self.degE, self.degV)
+                                       ca=1 - alpha, cb=alpha, degE=self.degE, degV=self.degV, relu=relu,
+                                       options=self.options)
+        Xv = UniGNNConvdeg(self.hyperg, X, self.degE, self.degV, options=self.options)
         Xi = (1 - alpha) * Xv + alpha * X0
         out = (1 - beta) * Xi + beta * self.W(Xi)
         return torch.relu(out) if relu else out
@@ -166,7 +176,9 @@ class HGsysHGNN(nn.Module):
         if getattr(args, "backend", "hgsys") == "torch":
             Conv, g = __torch_convs__[args.model], _TorchGraph(hyperg, getattr(args, "device", hyperg.device))
         else:
-            Conv, g = __hgsys_convs__[args.model], hyperg
+            import functools
+            # args.options (an ops.Options) pins this model's kernel family / backward rule / linear folding
+            Conv, g = functools.partial(__hgsys_convs__[args.model], options=getattr(args, "options", None)), hyperg
         self.conv_out = Conv(g, nhid * nhead, nclass, first_aggr, nhead)
         self.convs = nn.ModuleList([Conv(g, nfeat, nhid, first_aggr, nhead)] +
                                    [Conv(g, nhid * nhead, nhid, first_aggr, nhead) for _ in range(nlayer - 2)])
@@ -196,7 +208,8 @@ class UniGCNII(nn.Module):
             tg = _TorchGraph(hyperg, getattr(args, "device", hyperg.device))
             self.convs.extend(TorchGCNIIConv(tg, nhid, nhid) for _ in range(nlayer))
         else:
-            self.convs.extend(HyperGsysUniGCNII(hyperg, nhid, nhid) for _ in range(nlayer))
+            self.convs.extend(HyperGsysUniGCNII(hyperg, nhid, nhid, options=getattr(args, "options", None))
+                              for _ in range(nlayer))
         self.convs.append(lin(nhid, nclass))
         self.reg_params = list(self.convs[1:-1].parameters())
         self.non_reg_params = list(self.convs[0:1].parameters()) + list(self.convs[-1:].parameters())

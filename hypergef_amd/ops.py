@@ -27,34 +27,94 @@ from . import _lib
 from .plan import (Plan, cached_plan, linear_fusion_pays, linear_rows, linear_supported, linear_wgrad,
                    wgrad_supported, _check_feat, _check_index, _ptr, _stream_handle)
 
+import contextlib
+import dataclasses
 import os as _os
+import threading
 
-_STATE = {"variant": "auto", "backward": "reference", "fuse_linear": "auto"}
-if _os.environ.get("HG_FUSE_LINEAR") in ("auto", "always", "never"):  # A/B runs of the drivers
-    _STATE["fuse_linear"] = _os.environ["HG_FUSE_LINEAR"]
+
+@dataclasses.dataclass(frozen=True)
+class Options:
+    """How one operator call runs: kernel family, backward rule, linear folding.
+
+    variant:     'auto' | 'pull' | 'fused' | 'push_atomic' (one task per hyperedge) | 'push_groups'
+                 (the caller's group_* tensors drive the push kernel).
+    backward:    'reference' (forward(grad_out), hgnnaggr.cc:51-64) | 'adjoint' (the exact transpose).
+    fuse_linear: 'auto' folds a layer's projection into the aggregation where that is faster
+                 (plan.linear_fusion_pays), 'always' wherever the kernel takes the widths, 'never' not.
+
+    Every operator resolves its options per call -- an explicit `options=` argument, else the innermost
+    `with ops.options(...)` block of the calling thread, else the process defaults -- and an autograd node keeps
+    the options of its forward for its backward, whichever thread runs it.  Two models in one process can
+    therefore differ; nothing is shared but the defaults."""
+    variant: str = "auto"
+    backward: str = "reference"
+    fuse_linear: str = "auto"
+
+    _CHOICES = {"variant": ("auto", "pull", "fused", "push_atomic", "push_groups"),
+                "backward": ("reference", "adjoint"), "fuse_linear": ("auto", "always", "never")}
+
+    def __post_init__(self):
+        for k, allowed in Options._CHOICES.items():
+            if getattr(self, k) not in allowed:
+                raise ValueError("%s must be one of %s, got %r" % (k, ", ".join(allowed), getattr(self, k)))
+
+    def replace(self, **kw):
+        return dataclasses.replace(self, **kw)
+
+
+_DEFAULTS_LOCK = threading.Lock()
+_DEFAULTS = Options(fuse_linear=_os.environ["HG_FUSE_LINEAR"]
+                    if _os.environ.get("HG_FUSE_LINEAR") in ("auto", "always", "never") else "auto")  # A/B runs of the drivers
+_TLS = threading.local()
+
+
+def current_options():
+    """The options a call made here, now, without an explicit `options=` would run with."""
+    stack = getattr(_TLS, "stack", None)
+    return stack[-1] if stack else _DEFAULTS
+
+
+@contextlib.contextmanager
+def options(**kw):
+    """`with ops.options(variant="pull", backward="adjoint"):` -- per-thread, nestable overrides."""
+    stack = getattr(_TLS, "stack", None)
+    if stack is None:
+        stack = _TLS.stack = []
+    stack.append(current_options().replace(**kw))
+    try:
+        yield stack[-1]
+    finally:
+        stack.pop()
+
+
+def _opt(o):
+    if o is None:
+        return current_options()
+    if not isinstance(o, Options):
+        raise TypeError("options must be an ops.Options")
+    return o
+
+
+def _set_default(**kw):
+    global _DEFAULTS
+    with _DEFAULTS_LOCK:
+        _DEFAULTS = _DEFAULTS.replace(**kw)
 
 
 def set_variant(name):
-    """'auto' | 'pull' | 'fused' | 'push_atomic' (one task per hyperedge) | 'push_groups'
-    (the caller's group_* tensors drive the reference-style kernel)."""
-    if name not in ("auto", "pull", "fused", "push_atomic", "push_groups"):
-        raise ValueError("unknown variant %r" % (name,))
-    _STATE["variant"] = name
+    """Process default of Options.variant (see there)."""
+    _set_default(variant=name)
 
 
 def set_backward(mode):
-    if mode not in ("reference", "adjoint"):
-        raise ValueError("backward mode must be 'reference' or 'adjoint'")
-    _STATE["backward"] = mode
+    """Process default of Options.backward."""
+    _set_default(backward=mode)
 
 
 def set_fuse_linear(mode):
-    """hgnnaggr_linear / HGNNAggrLinear: 'auto' folds the projection into the aggregation where that
-    is faster (plan.linear_fusion_pays), 'always' wherever the kernel takes the widths, 'never' runs
-    linear-then-aggregate."""
-    if mode not in ("auto", "always", "never"):
-        raise ValueError("fuse_linear mode must be 'auto', 'always' or 'never'")
-    _STATE["fuse_linear"] = mode
+    """Process default of Options.fuse_linear."""
+    _set_default(fuse_linear=mode)
 
 
 def _flat(t):
@@ -62,7 +122,7 @@ def _flat(t):
     return None if t is None else t.reshape(-1)
 
 
-def _forward(sched, csrptr_t, indices_t, node_feat, degE, degV, W):
+def _forward(sched, csrptr_t, indices_t, node_feat, degE, degV, W, opt):
     _check_feat(node_feat, "node_feat")
     _check_index(csrptr_t, "csrptr_t")
     _check_index(indices_t, "indices_t")
@@ -70,7 +130,7 @@ def _forward(sched, csrptr_t, indices_t, node_feat, degE, degV, W):
         raise ValueError("node_feat must be [N, F]")
     N, F = node_feat.shape
     degE, degV, W = _flat(degE), _flat(degV), _flat(W)
-    variant = _STATE["variant"]
+    variant = opt.variant
     if variant == "push_groups":
         key, row, st, ed = sched
         for n, t in (("balan_key", key), ("balan_row", row), ("group_st", st), ("group_ed", ed)):
@@ -97,9 +157,10 @@ class _SumAggr(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, balan_key, balan_row, group_st, group_ed, csrptr_t, indices_t, node_feat,
-                degE, degV, W):
+                degE, degV, W, opt=None):
+        opt = ctx.opt = _opt(opt)
         out = _forward((balan_key, balan_row, group_st, group_ed), csrptr_t, indices_t, node_feat,
-                       degE, degV, W)
+                       degE, degV, W, opt)
         # The reference saves its inputs the same way (hgnnaggr.cc:44-46); node_feat is not needed
         # (the operator is linear).  save_for_backward makes autograd raise if one of them is
         # modified in place between forward and backward.
@@ -111,18 +172,18 @@ class _SumAggr(torch.autograd.Function):
         grad_out = grad_out.contiguous()
         balan_key, balan_row, group_st, group_ed, csrptr_t, indices_t, degE, degV, W = ctx.saved_tensors
         sched = (balan_key, balan_row, group_st, group_ed)
-        if _STATE["backward"] == "reference" or degV is None:
-            g = _forward(sched, csrptr_t, indices_t, grad_out, degE, degV, W)
+        if ctx.opt.backward == "reference" or degV is None:
+            g = _forward(sched, csrptr_t, indices_t, grad_out, degE, degV, W, ctx.opt)
         else:
-            g = _forward(sched, csrptr_t, indices_t, grad_out * degV.reshape(-1, 1), degE, None, W)
-        return (None,) * 6 + (g, None, None, None)
+            g = _forward(sched, csrptr_t, indices_t, grad_out * degV.reshape(-1, 1), degE, None, W, ctx.opt)
+        return (None,) * 6 + (g, None, None, None, None)
 
 
-def _rows_times(A, B):
+def _rows_times(A, B, mode="auto"):
     """A . B for tall-skinny A [N, K], B [K, F]: the library's MFMA rows kernel where it takes the
     widths (1.4-1.5x rocBLAS at K <= 64), torch otherwise.  Backward-pass GEMMs use it."""
     K, F = B.shape
-    if _STATE["fuse_linear"] != "never" and A.is_cuda and linear_supported(K, F) and A.shape[0] >= 4096:
+    if mode != "never" and A.is_cuda and linear_supported(K, F) and A.shape[0] >= 4096:
         return linear_rows(A.contiguous(), B.t().contiguous())
     return A @ B
 
@@ -132,11 +193,11 @@ def _pad16(t):
     return t if pad == 0 else torch.nn.functional.pad(t, (0, pad))
 
 
-def _wgrad(A, B):
+def _wgrad(A, B, mode="auto"):
     """A^T . B over the vertices (the linear's weight gradient): the library's streaming MFMA kernel
     where it takes the widths -- rocBLAS needs 1.2 ms for [64 x 693 k] x [693 k x 64], 17x the time of
     reading the operands -- torch otherwise."""
-    if _STATE["fuse_linear"] != "never" and A.is_cuda and A.shape[0] >= 4096:
+    if mode != "never" and A.is_cuda and A.shape[0] >= 4096:
         Fa, Fb = A.shape[1], B.shape[1]
         if wgrad_supported(Fa, Fb):
             return linear_wgrad(A.contiguous(), B.contiguous())
@@ -154,14 +215,15 @@ class _LinearFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.mode = current_options().fuse_linear
         return torch.nn.functional.linear(x, weight, bias)
 
     @staticmethod
     def backward(ctx, grad):
         x, weight = ctx.saved_tensors
         grad = grad.contiguous()
-        gx = _rows_times(grad, weight) if ctx.needs_input_grad[0] else None
-        gw = _wgrad(grad, x) if ctx.needs_input_grad[1] else None
+        gx = _rows_times(grad, weight, ctx.mode) if ctx.needs_input_grad[0] else None
+        gw = _wgrad(grad, x, ctx.mode) if ctx.needs_input_grad[1] else None
         gb = grad.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return gx, gw, gb
 
@@ -185,7 +247,8 @@ class _SumAggrLinear(torch.autograd.Function):
     mode, as _SumAggr), dX = dZ . Wlin, dWlin = dZ^T . X."""
 
     @staticmethod
-    def forward(ctx, csrptr_t, indices_t, node_feat, weight, degE, degV, W):
+    def forward(ctx, csrptr_t, indices_t, node_feat, weight, degE, degV, W, opt=None):
+        opt = ctx.opt = _opt(opt)
         _check_feat(node_feat, "node_feat")
         _check_feat(weight, "weight", device=node_feat.device)
         _check_index(csrptr_t, "csrptr_t")
@@ -195,9 +258,9 @@ class _SumAggrLinear(torch.autograd.Function):
         degE, degV, W = _flat(degE), _flat(degV), _flat(W)
         N, F_in = node_feat.shape
         F_out = weight.shape[0]
-        variant = _STATE["variant"]
+        variant = opt.variant
         plan = cached_plan(N, csrptr_t, indices_t)
-        mode = _STATE["fuse_linear"]
+        mode = opt.fuse_linear
         fuse = (mode == "always" and linear_supported(F_in, F_out)) or \
                (mode == "auto" and linear_fusion_pays(F_in, F_out))
         if fuse and variant in ("auto", "pull", "fused"):
@@ -207,14 +270,14 @@ class _SumAggrLinear(torch.autograd.Function):
             wd = weight.detach().contiguous()
             Z = linear_rows(node_feat, wd) if linear_supported(F_in, F_out) and mode != "never" \
                 else torch.nn.functional.linear(node_feat, wd)
-            out = _SumAggrLinear._aggr(csrptr_t, indices_t, Z, degE, degV, W)
+            out = _SumAggrLinear._aggr(csrptr_t, indices_t, Z, degE, degV, W, opt)
         ctx.save_for_backward(node_feat, weight, csrptr_t, indices_t, degE, degV, W)
         return out
 
     @staticmethod
-    def _aggr(csrptr_t, indices_t, feat, degE, degV, W):
+    def _aggr(csrptr_t, indices_t, feat, degE, degV, W, opt):
         # this operator has no group_* tensors: "push_groups" falls back to the plan's own schedule
-        variant = _STATE["variant"] if _STATE["variant"] != "push_groups" else "auto"
+        variant = opt.variant if opt.variant != "push_groups" else "auto"
         plan = cached_plan(feat.shape[0], csrptr_t, indices_t)
         return plan.aggregate(csrptr_t, indices_t, feat.contiguous(), degE, degV, W, variant=variant)
 
@@ -222,13 +285,14 @@ class _SumAggrLinear(torch.autograd.Function):
     def backward(ctx, grad_out):
         grad_out = grad_out.contiguous()
         node_feat, weight, csrptr_t, indices_t, degE, degV, W = ctx.saved_tensors
-        if _STATE["backward"] == "reference" or degV is None:
-            dZ = _SumAggrLinear._aggr(csrptr_t, indices_t, grad_out, degE, degV, W)
+        opt = ctx.opt
+        if opt.backward == "reference" or degV is None:
+            dZ = _SumAggrLinear._aggr(csrptr_t, indices_t, grad_out, degE, degV, W, opt)
         else:
-            dZ = _SumAggrLinear._aggr(csrptr_t, indices_t, grad_out * degV.reshape(-1, 1), degE, None, W)
-        gx = _rows_times(dZ, weight) if ctx.needs_input_grad[2] else None
-        gw = _wgrad(dZ, node_feat) if ctx.needs_input_grad[3] else None
-        return None, None, gx, gw, None, None, None
+            dZ = _SumAggrLinear._aggr(csrptr_t, indices_t, grad_out * degV.reshape(-1, 1), degE, None, W, opt)
+        gx = _rows_times(dZ, weight, opt.fuse_linear) if ctx.needs_input_grad[2] else None
+        gw = _wgrad(dZ, node_feat, opt.fuse_linear) if ctx.needs_input_grad[3] else None
+        return None, None, gx, gw, None, None, None, None
 
 
 class _AggrResLinear(torch.autograd.Function):
@@ -241,7 +305,8 @@ class _AggrResLinear(torch.autograd.Function):
     dcb = <dT, R> (cb may be a tensor, e.g. 1 + eps)."""
 
     @staticmethod
-    def forward(ctx, csrptr_t, indices_t, node_feat, M, R, cb, degE, degV, W, ca, relu, need_t):
+    def forward(ctx, csrptr_t, indices_t, node_feat, M, R, cb, degE, degV, W, ca, relu, need_t, opt=None):
+        opt = ctx.opt = _opt(opt)
         _check_feat(node_feat, "node_feat")
         _check_index(csrptr_t, "csrptr_t")
         _check_index(indices_t, "indices_t")
@@ -251,10 +316,10 @@ class _AggrResLinear(torch.autograd.Function):
         # cb is a Python float except where it is learned (UniGIN's 1 + eps): only then does reading
         # it cost a device-to-host sync
         cbf = float(cb) if R is not None else 0.0
-        variant = _STATE["variant"] if _STATE["variant"] != "push_groups" else "auto"
+        variant = opt.variant if opt.variant != "push_groups" else "auto"
         Md = M.detach().contiguous()
         Rd = None if R is None else R.detach().contiguous()
-        mode = _STATE["fuse_linear"]
+        mode = opt.fuse_linear
         fuse = (mode == "always" and linear_supported(F_in, F_out)) or \
                (mode == "auto" and linear_fusion_pays(F_in, F_out))
         if fuse and variant in ("auto", "pull", "fused"):
@@ -263,7 +328,7 @@ class _AggrResLinear(torch.autograd.Function):
             out = plan.aggregate_linear(csrptr_t, indices_t, node_feat.detach(), Md, degE, degV, W, variant=variant,
                                         residual=Rd, ca=ca, cb=cbf, relu=relu, t_out=T)
         else:
-            T = _SumAggrLinear._aggr(csrptr_t, indices_t, node_feat.detach(), degE, degV, W) * ca
+            T = _SumAggrLinear._aggr(csrptr_t, indices_t, node_feat.detach(), degE, degV, W, opt) * ca
             if Rd is not None:
                 T = T + Rd * cbf
             out = T @ Md.t()
@@ -280,22 +345,23 @@ class _AggrResLinear(torch.autograd.Function):
         dP = grad_out.contiguous()
         if relu:
             dP = torch.ops.aten.threshold_backward(dP, out, 0.0)  # relu's own backward: one vectorised kernel
-        dT = _rows_times(dP, M)
-        gM = _wgrad(dP, T) if ctx.needs_input_grad[3] else None
+        opt = ctx.opt
+        dT = _rows_times(dP, M, opt.fuse_linear)
+        gM = _wgrad(dP, T, opt.fuse_linear) if ctx.needs_input_grad[3] else None
         gx = None
         if ctx.needs_input_grad[2]:
             g_in = dT * ca
-            if _STATE["backward"] == "reference" or degV is None:
-                gx = _SumAggrLinear._aggr(csrptr_t, indices_t, g_in, degE, degV, W)
+            if opt.backward == "reference" or degV is None:
+                gx = _SumAggrLinear._aggr(csrptr_t, indices_t, g_in, degE, degV, W, opt)
             else:
-                gx = _SumAggrLinear._aggr(csrptr_t, indices_t, g_in * degV.reshape(-1, 1), degE, None, W)
+                gx = _SumAggrLinear._aggr(csrptr_t, indices_t, g_in * degV.reshape(-1, 1), degE, None, W, opt)
         gR = dT * cbf if (R is not None and ctx.needs_input_grad[4]) else None
         gcb = (dT * R).sum() if (R is not None and ctx.needs_input_grad[5]) else None
-        return None, None, gx, gM, gR, gcb, None, None, None, None, None, None
+        return None, None, gx, gM, gR, gcb, None, None, None, None, None, None, None
 
 
 def aggr_res_linear(csrptr_t, indices_t, node_feat, M, residual=None, ca=1.0, cb=0.0, degE=None, degV=None, W=None,
-                    relu=False):
+                    relu=False, options=None):
     """act((ca * Aggr(node_feat) + cb * residual) . M^T) in one pass where the widths allow
     (include/hg_aggr.h, hg_aggr_linear_res_f32).  cb may be a tensor (its gradient is returned)."""
     # a Python-number cb goes through as it is (no host-to-device copy, no sync to read it back)
@@ -305,22 +371,23 @@ def aggr_res_linear(csrptr_t, indices_t, node_feat, M, residual=None, ca=1.0, cb
     need_t = torch.is_grad_enabled() and any(
         isinstance(t, torch.Tensor) and t.requires_grad for t in (node_feat, M, residual, cb_a))
     return _AggrResLinear.apply(csrptr_t, indices_t, node_feat, M, residual, cb_a, degE, degV, W, float(ca),
-                                bool(relu), need_t)
+                                bool(relu), need_t, _opt(options))
 
 
-def hgnnaggr_linear(csrptr_t, indices_t, node_feat, weight, degE=None, degV=None, W=None):
+def hgnnaggr_linear(csrptr_t, indices_t, node_feat, weight, degE=None, degV=None, W=None, options=None):
     """Aggr(node_feat . weight^T) with the projection folded into the aggregation
     (include/hg_aggr.h, hg_aggr_linear_f32).  degE / degV / W optional: all three = hgnnaggr,
     degE + degV = unignnaggrdeg, none = unignnaggr."""
-    return _SumAggrLinear.apply(csrptr_t, indices_t, node_feat, weight, degE, degV, W)
+    return _SumAggrLinear.apply(csrptr_t, indices_t, node_feat, weight, degE, degV, W, _opt(options))
 
 
 # ---- module `hgnnaggr` (hgnnaggr.cc:122-151) ---------------------------------
 
-def hgnnaggr(balan_key, balan_row, group_st, group_ed, csrptr_t, indices_t, node_feat, degE, degV, W):
-    """hgnnaggr with fused degE and degV."""
+def hgnnaggr(balan_key, balan_row, group_st, group_ed, csrptr_t, indices_t, node_feat, degE, degV, W, options=None):
+    """hgnnaggr with fused degE and degV.  (`options`: this backend's per-call Options; the reference's ten
+    positional arguments are unchanged.)"""
     return _SumAggr.apply(balan_key, balan_row, group_st, group_ed, csrptr_t, indices_t, node_feat,
-                          degE, degV, W)
+                          degE, degV, W, _opt(options))
 
 
 def _edge_sizes(csrptr_t):
@@ -402,14 +469,14 @@ def hgnnaggr_max(csrptr_t, indices_t, node_feat, degE, degV, W):
 
 # ---- module `unignnaggr` (unignnaggr.cc:81-102) ------------------------------
 
-def unignnaggrdeg(balan_key, balan_row, group_st, group_ed, csrptr_t, indices_t, node_feat, degE, degV):
+def unignnaggrdeg(balan_key, balan_row, group_st, group_ed, csrptr_t, indices_t, node_feat, degE, degV, options=None):
     return _SumAggr.apply(balan_key, balan_row, group_st, group_ed, csrptr_t, indices_t, node_feat,
-                          degE, degV, None)
+                          degE, degV, None, _opt(options))
 
 
-def unignnaggr(balan_key, balan_row, group_st, group_ed, csrptr_t, indices_t, node_feat):
+def unignnaggr(balan_key, balan_row, group_st, group_ed, csrptr_t, indices_t, node_feat, options=None):
     return _SumAggr.apply(balan_key, balan_row, group_st, group_ed, csrptr_t, indices_t, node_feat,
-                          None, None, None)
+                          None, None, None, _opt(options))
 
 
 # the names the reference's Python wrapper actually calls (unignnconv.py:7,10);
@@ -420,28 +487,28 @@ unignnconv = unignnaggr
 
 # ---- wrappers (source/python/hgnnaggr.py, unignnconv.py) ----------------------
 
-def HGNNAggr(hyperg, in_feat, degE, degV, Wdiag, first_aggr="sum"):
+def HGNNAggr(hyperg, in_feat, degE, degV, Wdiag, first_aggr="sum", options=None):
     """first_aggr is accepted and ignored, as in the reference (hgnnaggr.py:6-7);
     it has a default so the reference test's 5-argument call works (hgnn_test.py:89)."""
     return hgnnaggr(hyperg.group_key, hyperg.group_row, hyperg.group_start, hyperg.group_end,
-                    hyperg.H_T_csrptr, hyperg.H_T_colind, in_feat, degE, degV, Wdiag)
+                    hyperg.H_T_csrptr, hyperg.H_T_colind, in_feat, degE, degV, Wdiag, options=options)
 
 
-def HGNNAggrLinear(hyperg, in_feat, weight, degE, degV, Wdiag):
+def HGNNAggrLinear(hyperg, in_feat, weight, degE, degV, Wdiag, options=None):
     """HGNNAggr(hyperg, in_feat . weight^T, ...) in one pass."""
-    return hgnnaggr_linear(hyperg.H_T_csrptr, hyperg.H_T_colind, in_feat, weight, degE, degV, Wdiag)
+    return hgnnaggr_linear(hyperg.H_T_csrptr, hyperg.H_T_colind, in_feat, weight, degE, degV, Wdiag, options=options)
 
 
-def UniGNNConvLinear(dl, in_feat, weight):
+def UniGNNConvLinear(dl, in_feat, weight, options=None):
     """UniGNNConv(dl, in_feat . weight^T) in one pass."""
-    return hgnnaggr_linear(dl.H_T_csrptr, dl.H_T_colind, in_feat, weight)
+    return hgnnaggr_linear(dl.H_T_csrptr, dl.H_T_colind, in_feat, weight, options=options)
 
 
-def UniGNNConvdeg(dl, in_feat, degE, degV):
+def UniGNNConvdeg(dl, in_feat, degE, degV, options=None):
     return unignnaggrdeg(dl.group_key, dl.group_row, dl.group_start, dl.group_end,
-                         dl.H_T_csrptr, dl.H_T_colind, in_feat, degE, degV)
+                         dl.H_T_csrptr, dl.H_T_colind, in_feat, degE, degV, options=options)
 
 
-def UniGNNConv(dl, in_feat):
+def UniGNNConv(dl, in_feat, options=None):
     return unignnaggr(dl.group_key, dl.group_row, dl.group_start, dl.group_end,
-                      dl.H_T_csrptr, dl.H_T_colind, in_feat)
+                      dl.H_T_csrptr, dl.H_T_colind, in_feat, options=options)

@@ -388,6 +388,13 @@ def packed_linear_cached(weight):
     return packed
 
 
+def clear_pack_cache():
+    """Forget every cached packing.  Needed around hipGraph captures that update weights: a replay rewrites the
+    weights in place behind torch's version counter, which is part of the cache key."""
+    with _CACHE_LOCK:
+        _PACK_CACHE.clear()
+
+
 def linear_rows(X, weight, packed=None, out=None):
     """X . weight^T on the library's own fp32-MFMA rows kernel (hg_linear_rows_f32): for the
     tall-skinny products of this path it is 1.1-1.5x rocBLAS at K <= 64 and on par at K = 128."""

@@ -257,10 +257,14 @@ def test_errors_raise_not_abort(hg):
         plan.aggregate(ptr, ind, torch.zeros(inc.N, 8, device=DEV, dtype=torch.float64))
     with pytest.raises(RuntimeError):
         plan.aggregate(ptr, ind, torch.zeros(8, inc.N, device=DEV).t())
+    # the workspace is checked against the layout that runs: the pull pair needs Xe [M, F], this graph's fused
+    # schedule (nothing materialised, no partial rows) needs none at all
+    small = torch.empty(256, dtype=torch.uint8, device=DEV)
     with pytest.raises(_lib.HgError) as ei:
-        plan.aggregate(ptr, ind, torch.zeros(inc.N, 8, device=DEV),
-                       workspace=torch.empty(256, dtype=torch.uint8, device=DEV))
+        plan.aggregate(ptr, ind, torch.zeros(inc.N, 8, device=DEV), workspace=small, variant="pull")
     assert ei.value.status == -4
+    assert plan.auto_variant(8) == "fused" and plan.prepare(8)["n_mat"] == 0
+    assert not plan.aggregate(ptr, ind, torch.zeros(inc.N, 8, device=DEV), workspace=small).any()
     bad = ind.clone()
     bad[0] = inc.N + 5
     with pytest.raises(_lib.HgError):
@@ -784,6 +788,43 @@ def test_own_linear_module_matches_nn_linear(hg):
 
 # ---- round 2: BASELINE configs 4 and 5 at full size, the sharded HIP path, the drop-in modules ----
 
+def test_hub_pass_counts_duplicate_incidences(hg, oracle):
+    """A vertex listed twice in a hyperedge counts twice (validate_csr and the MatrixMarket reader keep duplicates
+    of `general` files).  The hub pass once fed its flag-driven heavy hubs one contribution per hyperedge: here
+    the two heaviest vertices of a power-law hypergraph that reaches the hub pass are listed twice in a fifth of
+    their hyperedges, a further 1 % of all incidences are doubled at random, and every path must agree with the
+    float64 answer and with the pull variant."""
+    from hypergef_amd.plan import Plan, make_opts
+    base = synth.powerlaw(80_000, 300_000, seed=5)
+    rng = np.random.default_rng(77)
+    deg = np.bincount(base.colind, minlength=base.N)
+    heavy = np.argsort(-deg)[:2]
+    eid = np.repeat(np.arange(base.M), np.diff(base.csrptr))
+    dup = (np.isin(base.colind, heavy) & (rng.random(base.nnz) < 0.2)) | (rng.random(base.nnz) < 0.01)
+    reps = np.where(dup, 2, 1)
+    colind = np.repeat(base.colind, reps)
+    csrptr = np.zeros(base.M + 1, np.int64)
+    np.add.at(csrptr, eid + 1, reps)
+    inc = synth.Incidence(base.N, base.M, np.cumsum(csrptr).astype(np.int32), colind.astype(np.int32), name="powerlaw+dups")
+    assert inc.nnz > base.nnz + 20_000
+    F = 32
+    X = rng.standard_normal((inc.N, F)).astype(np.float32)
+    ptr, ind, Xd = _dev(inc.csrptr), _dev(inc.colind), _dev(X)
+    plan = Plan.from_tensors(inc.N, ptr, ind)
+    info = plan.prepare(F)
+    assert info["n_hub"] > 100 and info["hub_rounds"] > 100, info
+    truth = _float64_truth(inc, X)
+    mass = _float64_truth(inc, np.abs(X))
+    y = plan.aggregate(ptr, ind, Xd, variant="fused").cpu().numpy()
+    worst = np.abs(y - truth) / np.maximum(1.0, mass)
+    assert worst.max() <= 1e-5, "row %d (degree %d) off by %g of its mass" % (worst.max(1).argmax(), deg[worst.max(1).argmax()], worst.max())
+    yp = plan.aggregate(ptr, ind, Xd, variant="pull").cpu().numpy()
+    assert (np.abs(yp - truth) <= 1e-5 * np.maximum(1.0, mass)).all()
+    no_hub = Plan.from_tensors(inc.N, ptr, ind, make_opts(hub_pass=False))
+    y2 = no_hub.aggregate(ptr, ind, Xd, variant="fused").cpu().numpy()
+    assert (np.abs(y2 - truth) <= 1e-5 * np.maximum(1.0, mass)).all()
+
+
 def _float64_truth(inc, X, degE=None, degV=None, W=None):
     """Dv H De W H^T X in float64 (scipy): the exact answer the fp32 paths are measured against
     where their summation orders differ (rows of 10^5..10^6 terms)."""
@@ -942,6 +983,82 @@ def test_sharded_aggregator_two_ranks_share_the_gpu(hg, tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert all((tmp_path / ("ok%d" % k)).exists() for k in range(2))
+
+
+def test_options_are_per_call_and_follow_the_forward_into_backward(hg, oracle):
+    """Kernel family / backward rule / linear folding are per call (ops.Options): an explicit `options=`, else the
+    calling thread's `with ops.options(...)`, else the process defaults -- and an autograd node runs its backward
+    under the options of its forward, outside the block that set them.  Two models in one process differ."""
+    import threading
+    import types
+    from hypergef_amd import models, ops
+    inc = _make("cora")
+    F = 16
+    X, degE, degV, W, H_ptr, H_ind = _inputs(inc, F, oracle, seed=18, normal=True)
+    hyperg = hg.HyperGraph.from_incidence(inc, DEV, data_name="cora")
+    g = torch.from_numpy(np.random.default_rng(19).standard_normal((inc.N, F)).astype(np.float32)).to(DEV)
+    ref = oracle.hgnn_check(inc.N, inc.M, F, H_ptr, H_ind, inc.csrptr, inc.colind, X, degE, degV, W)
+    ref_bwd = oracle.hgnn_check(inc.N, inc.M, F, H_ptr, H_ind, inc.csrptr, inc.colind, g.cpu().numpy(), degE, degV, W)
+    gv = (g.cpu().numpy() * degV).astype(np.float32)
+    ref_adj = oracle.hgnn_check(inc.N, inc.M, F, H_ptr, H_ind, inc.csrptr, inc.colind, gv, degE, None, W)
+    assert ops.current_options() == ops.Options()
+    # explicit options on the reference's own wrapper; the defaults stay untouched
+    for variant in ("pull", "fused", "push_atomic", "push_groups"):
+        y = hg.HGNNAggr(hyperg, _dev(X), hyperg.degE, hyperg.degV, _dev(W), options=ops.Options(variant=variant))
+        _assert_close(y, ref)
+    assert ops.current_options() == ops.Options()
+    # forward inside a block, backward outside it: the node remembers "adjoint"
+    x1 = _dev(X).requires_grad_(True)
+    with ops.options(backward="adjoint", variant="pull") as o:
+        assert ops.current_options() is o and o.variant == "pull"
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(ops.current_options()))
+        t.start()
+        t.join()
+        assert seen[0] == ops.Options()  # another thread is not affected
+        y1 = hg.HGNNAggr(hyperg, x1, hyperg.degE, hyperg.degV, _dev(W))
+    assert ops.current_options() == ops.Options()
+    y1.backward(g)
+    _assert_close(x1.grad, ref_adj)
+    x2 = _dev(X).requires_grad_(True)
+    hg.HGNNAggr(hyperg, x2, hyperg.degE, hyperg.degV, _dev(W)).backward(g)
+    _assert_close(x2.grad, ref_bwd)
+    with pytest.raises(ValueError):
+        ops.Options(variant="bogus")
+    with pytest.raises(TypeError):
+        hg.HGNNAggr(hyperg, _dev(X), hyperg.degE, hyperg.degV, _dev(W), options="pull")
+    # two models in one process, each with its own options
+    def net(opt):
+        a = types.SimpleNamespace(model="HGNN", activation="relu", input_drop=0.0, dropout=0.0, backend="hgsys", options=opt)
+        torch.manual_seed(5)
+        return models.HGsysHGNN(a, hyperg, F, 32, 7, 2, "sum", 1).to(DEV).eval()
+    m_two_step = net(ops.Options(variant="pull", fuse_linear="never"))
+    m_fused = net(ops.Options(variant="fused", fuse_linear="always"))
+    assert m_two_step.convs[0].options.variant == "pull" and m_fused.convs[0].options.fuse_linear == "always"
+    with torch.no_grad():
+        za, zb = m_two_step(_dev(X)), m_fused(_dev(X))
+    assert torch.allclose(za, zb, rtol=1e-4, atol=1e-4) and ops.current_options() == ops.Options()
+
+
+def test_rccl_branches_execute_at_world_size_one(hg, tmp_path):
+    """The `nccl` (= RCCL) branches of hypergef_amd.dist on the one GPU there is: a child process initialises a
+    one-rank RCCL process group before touching the GPU and runs every exchange form with force_collective=True
+    -- all-reduce, reduce_scatter_tensor, the asynchronous column-pipelined forms, all_gather, backward -- against
+    the oracle (tests/_rccl_child.py); the child counts the collectives that reached the process group."""
+    import json, os, socket, subprocess, sys
+    from conftest import ROOT
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl_child.py"), str(tmp_path)],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    rec = json.load(open(tmp_path / "rccl_world1.json"))
+    assert rec["backend"] == "nccl" and rec["world"] == 1
+    assert rec["collective_calls"] == {"all_reduce": 7, "reduce_scatter_tensor": 3, "all_gather": 1}
 
 
 def test_dropin_modules_import_in_a_fresh_interpreter(hg):

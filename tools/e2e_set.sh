@@ -16,4 +16,11 @@ for m in HGNN UniGIN UniGCNII; do for b in hgsys torch; do
   python tools/hgsys.py --model $m --backend $b --dname cora --epochs 100 --graph --output $g > /dev/null 2>&1
 done; done
 for b in hgsys torch; do python tools/hgsys.py --model HGNN --backend $b --dname pubmed --nhid 128 --epochs 100 --graph --output $g > /dev/null 2>&1; done
+# the same models with the training step captured as well (forward, loss, backward, Adam: one replay per epoch)
+t=${out%.csv}_graph_train.csv; rm -f $t
+for m in HGNN UniGCNII; do for b in hgsys torch; do
+  python tools/hgsys.py --model $m --backend $b --dname cora --epochs 100 --graph --graph-train --output $t 2>&1 | grep -i "graph capture" 
+done; done
+for b in hgsys torch; do python tools/hgsys.py --model HGNN --backend $b --dname pubmed --nhid 128 --epochs 100 --graph --graph-train --output $t 2>&1 | grep -i "graph capture"; done
 cat $out; echo "-- with --graph (last column: hipGraph replay)"; cat $g
+echo "-- with --graph --graph-train (both columns: hipGraph replay)"; cat $t

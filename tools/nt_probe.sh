@@ -1,0 +1,14 @@
+#!/bin/bash
+# Diagnostic build, same box: the DBG instance of the panel kernel with plain Y stores (bit 1024 = no-op) against
+# non-temporal Y stores (bit 64).  usage (GPU box): tools/nt_probe.sh "<bench flags>" ...
+root=$GRAFT_REPO_ROOT; [ -z "$root" ] && root=$(cd $(dirname $0)/.. && pwd)
+cd $root
+for wl in "$@"; do
+  echo "== $wl"
+  for rep in 1 2; do
+    for dbg in 1024 64; do
+      HG_FUSED_DEBUG=$dbg HG_AGGR_LIB=$root/hypergef_amd/lib/libhgaggr_tuning.so timeout -k 10 200 python3 bench.py $wl --steps 100 --warmup 10 --no-cpu-baseline --no-configs --no-extras --no-parity 2>/dev/null |
+        python3 -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('   debug %-5s ms %.4f frac %.3f' % ('$dbg', d['ms_per_step'], d['roofline']['frac']))"
+    done
+  done
+done
