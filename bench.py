@@ -71,6 +71,8 @@ def parse():
     p.add_argument("--no-hub-pass", action="store_true")
     p.add_argument("--no-row-stream", action="store_true")
     p.add_argument("--weighted", action="store_true", help="hgnnaggr (degE, degV, W) instead of H H^T X")
+    p.add_argument("--linear-out", type=int, default=0,
+                   help="fold the layer's linear feat -> N into the aggregation (hg_aggr_linear_f32: the MFMA path)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-parity", action="store_true", help="skip the oracle comparison of the timed output")
     p.add_argument("--no-extras", action="store_true", help="skip device-copy / single-graph / sharded extras")
@@ -552,7 +554,8 @@ def main():
     one = world == 1
     res, cpu, st = run_config(args.shape, args.replicas, F, args.weighted, args.variant, args.steps, args.warmup,
                               dev, sync, barrier, rank, opts_kw,
-                              want_cpu=one and not args.no_cpu_baseline, want_parity=one and not args.no_parity)
+                              want_cpu=one and not args.no_cpu_baseline, want_parity=one and not args.no_parity,
+                              linear_out=args.linear_out)
     wall = st["wall"]
     if world > 1:
         t = torch.tensor([wall], dtype=torch.float64, device=dev)
@@ -579,7 +582,7 @@ def main():
         out["parity"] = res["parity"]
     failed = "parity" in res and not res["parity"]["ok"]
 
-    if not args.no_extras:
+    if not args.no_extras and not args.linear_out:
         # What a plain device copy X -> Y (the 2NF term of B_alg, no gather, no index traffic)
         # takes on this box: the practical floor of any kernel that reads X and writes Y once.
         X, Y = st["X"], st["Y"]
@@ -608,7 +611,7 @@ def main():
                 ("citeseer", 256, 128, False, 0), ("pubmed", 64, 128, False, 0), ("pubmed", 64, 128, False, 128),
                 ("powerlaw", 1, 64, False, 0), (args.shape, args.replicas, F, True, 0)]
         for shape, reps, feat, weighted, lin in todo:
-            if (shape, reps, feat, weighted, lin) == (args.shape, args.replicas, F, args.weighted, 0):
+            if (shape, reps, feat, weighted, lin) == (args.shape, args.replicas, F, args.weighted, args.linear_out):
                 continue
             try:
                 r, c, s2 = run_config(shape, reps, feat, weighted, "auto", args.config_steps, 10, dev, sync, barrier,

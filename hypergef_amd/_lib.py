@@ -50,7 +50,7 @@ class PlanOpts(ctypes.Structure):
 
 
 class TuneInfo(ctypes.Structure):
-    _fields_ = [("variant", ctypes.c_int32), ("pull_hop_kernels", ctypes.c_int32), ("us", ctypes.c_float * 5),
+    _fields_ = [("variant", ctypes.c_int32), ("pull_hop_kernels", ctypes.c_int32), ("us", ctypes.c_float * 10),
                 ("reserved", ctypes.c_int32)]
 
 

@@ -96,6 +96,9 @@ int plan_upload(hg_plan *p) {
   if ((rc = upload(p->ind_v, &p->d_ind_v, p->device_bytes)) != HG_OK) return rc;
   for (int h = 0; h < 2; h++)
     if ((rc = sched_upload(p->sched[h], p->device_bytes)) != HG_OK) return rc;
+  if (p->has_lat)
+    for (int h = 0; h < 2; h++)
+      if ((rc = sched_upload(p->sched_lat[h], p->device_bytes)) != HG_OK) return rc;
   return HG_OK;
 }
 
@@ -267,7 +270,7 @@ Carve carve(const hg_plan *p, int32_t F) {
   size_t off = round256((size_t)p->M * F * sizeof(float));
   for (int h = 0; h < 2; h++) {
     c.part[h] = off;
-    off += round256((size_t)std::max(p->sched[h].nslots, p->stream_nslots[h]) * F * sizeof(float) + 16);  // + 16: see fused_carve
+    off += round256((size_t)std::max(std::max(p->sched[h].nslots, p->sched_lat[h].nslots), p->stream_nslots[h]) * F * sizeof(float) + 16);  // + 16: see fused_carve
   }
   c.total = off;
   return c;
@@ -427,14 +430,14 @@ int run_hop(const hg_plan *p, int hop, int32_t F, const int32_t *ptr, const int3
   // kernel loads through a range-checked descriptor and stores only the columns that exist
   const bool lanes16 = F % 4 == 0 || F > 8;
   const int64_t nsrc = hop == 0 ? p->N : p->M, sb = nsrc * F * 4;
-  bool tuned_off = false;  // hg_plan_tune_f32 found the panel / task kernel faster for this hop and width
+  int kind = 0;  // hg_plan_tune_f32's choice for this hop and width: 0 streaming, 1 panels + tasks, 2 latency schedule
   {
     hg_plan *mp = const_cast<hg_plan *>(p);
     std::lock_guard<std::mutex> lock(mp->auto_mu);
     auto it = mp->hop_kernel.find(F);
-    tuned_off = it != mp->hop_kernel.end() && ((it->second >> hop) & 1);
+    if (it != mp->hop_kernel.end()) kind = hop == 0 ? it->second % 3 : (it->second / 3) % 3;
   }
-  if (!tuned_off && lanes16 && F < (1 << 22) && nsrc < (1 << 24) && sb > 0 && sb < ((int64_t)1 << 31) && !(p->opts.flags & HG_PLAN_NO_ROW_STREAM)) {
+  if (kind == 0 && lanes16 && F < (1 << 22) && nsrc < (1 << 24) && sb > 0 && sb < ((int64_t)1 << 31) && !(p->opts.flags & HG_PLAN_NO_ROW_STREAM)) {
     const int32_t ng = 256 / (hg::fused_tile_row_floats(F, true) / 4);
     const hg::RowStream *rs = nullptr;
     int rc = get_row_stream(p, hop, ng, &rs);
@@ -466,8 +469,8 @@ int run_hop(const hg_plan *p, int hop, int32_t F, const int32_t *ptr, const int3
       return HG_OK;
     }
   }
-  return run_sched(p, p->sched[hop], F, ptr, ind, src, scaleA, scaleB, nullptr, nullptr, dst, partial,
-                   stream, hop == 1);
+  return run_sched(p, (kind == 2 && p->has_lat) ? p->sched_lat[hop] : p->sched[hop], F, ptr, ind, src, scaleA, scaleB,
+                   nullptr, nullptr, dst, partial, stream, hop == 1);
 }
 
 // pull_only: the call runs the pull layout whatever schedules exist (a forced HG_VARIANT_PULL, a single hop): a
@@ -529,6 +532,13 @@ int plan_build(hg_plan **out, int32_t N, int32_t M, const int32_t *csrptr_t,
     hg::transpose_csr(M, N, csrptr_t, colind_t, p->ptr_v, p->ind_v);
     hg::build_sched(M, csrptr_t, o, p->sched[0]);
     hg::build_sched(N, p->ptr_v.data(), o, p->sched[1]);
+    if (p->nnz <= (1 << 18) && o.short_max > hg::kLatShortMax) {
+      hg::Opts ol = o;
+      ol.short_max = hg::kLatShortMax;
+      hg::build_sched(M, csrptr_t, ol, p->sched_lat[0]);
+      hg::build_sched(N, p->ptr_v.data(), ol, p->sched_lat[1]);
+      p->has_lat = true;
+    }
     int64_t small = 0;
     for (int32_t e = 0; e < M; e++) {
       const int32_t len = csrptr_t[e + 1] - csrptr_t[e];
@@ -611,6 +621,7 @@ void hg_plan_destroy(hg_plan *p) {
   if (p->d_ptr_v) (void)hipFree(p->d_ptr_v);
   if (p->d_ind_v) (void)hipFree(p->d_ind_v);
   for (int h = 0; h < 2; h++) sched_free(p->sched[h]);
+  for (int h = 0; h < 2; h++) sched_free(p->sched_lat[h]);
   for (auto &kv : p->fused) fused_free(kv.second);
   for (auto &kv : p->row_streams) {
     void *ptrs[] = {kv.second.d_rec, kv.second.d_rec_tab, kv.second.d_fixups};
@@ -1079,15 +1090,18 @@ int hg_plan_tune_f32(const hg_plan *plan, int32_t F, const int32_t *csrptr_t, co
     hg::set_error("hg_plan_tune_f32: hipEventCreate failed");
     return HG_ERR_HIP;
   }
-  float us[5] = {-1.f, -1.f, -1.f, -1.f, -1.f};
+  constexpr int NC = 10;  // fused + 3 x 3 kernels of the two pull hops
+  float us[NC];
+  for (int c = 0; c < NC; c++) us[c] = -1.f;
   auto set_choice = [&](int32_t variant, int32_t mask) {
     std::lock_guard<std::mutex> lock(mp->auto_mu);
     mp->auto_choice[key] = variant;
     mp->hop_kernel[F] = mask;
   };
   rc = HG_OK;
-  for (int c = 0; c < 5 && rc == HG_OK; c++) {
+  for (int c = 0; c < NC && rc == HG_OK; c++) {
     const int32_t variant = c == 0 ? HG_VARIANT_FUSED : HG_VARIANT_PULL;
+    if (c > 0 && !plan->has_lat && ((c - 1) % 3 == 2 || (c - 1) / 3 == 2)) continue;  // no latency schedule for this plan
     if (c == 0) {  // the fused schedule may not exist for this plan / width / workspace: skip it then
       const hg::FusedSched *f = nullptr;
       if (get_fused(plan, F, key & 1, &f) != HG_OK || fused_carve(*f, F).total > workspace_bytes) continue;
@@ -1113,7 +1127,7 @@ int hg_plan_tune_f32(const hg_plan *plan, int32_t F, const int32_t *csrptr_t, co
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   int best = -1;
-  for (int c = 0; c < 5; c++)
+  for (int c = 0; c < NC; c++)
     if (us[c] >= 0.f && (best < 0 || us[c] < us[best])) best = c;
   if (rc != HG_OK || best < 0) {  // leave the static rule in place
     std::lock_guard<std::mutex> lock(mp->auto_mu);
@@ -1127,7 +1141,7 @@ int hg_plan_tune_f32(const hg_plan *plan, int32_t F, const int32_t *csrptr_t, co
   }
   // among the pull candidates keep the fastest hop kernels even if fused won: a forced HG_VARIANT_PULL uses them
   int best_pull = 1;
-  for (int c = 2; c < 5; c++)
+  for (int c = 2; c < NC; c++)
     if (us[c] >= 0.f && us[c] < us[best_pull]) best_pull = c;
   set_choice(best == 0 ? HG_VARIANT_FUSED : HG_VARIANT_PULL, best_pull - 1);
   // Y holds the last candidate's result: run the winner once more so the caller gets what AUTO now computes
@@ -1135,7 +1149,7 @@ int hg_plan_tune_f32(const hg_plan *plan, int32_t F, const int32_t *csrptr_t, co
   if (info) {
     info->variant = best == 0 ? HG_VARIANT_FUSED : HG_VARIANT_PULL;
     info->pull_hop_kernels = best_pull - 1;
-    for (int c = 0; c < 5; c++) info->us[c] = us[c];
+    for (int c = 0; c < NC; c++) info->us[c] = us[c];
     info->reserved = 0;
   }
   return rc;

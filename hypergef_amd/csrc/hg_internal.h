@@ -118,6 +118,7 @@ struct HubPass {
 // stream[steps * ng] (entry words as in a panel record; an empty row is one idle entry with the last
 // flag), dst[nslots] (output row, or bit 31 | partial row), sidx[nslots] (index of the row's scale
 // factors, -1 = none: chunks and empty rows).
+constexpr int kLatShortMax = 8;     // latency schedule (hg_plan::sched_lat): longer rows are wave tasks
 constexpr int kRowStreamChunk = 64;  // rows longer than this are cut into chunks (partial rows + fixups)
 
 struct SRec {
@@ -244,6 +245,10 @@ struct hg_plan {
   std::vector<int32_t> ptr_v, ind_v;  // H CSR (vertex -> hyperedges), host
   int32_t *d_ptr_v = nullptr, *d_ind_v = nullptr;
   hg::Sched sched[2];  // [0]: H_T rows = hyperedges, [1]: H rows = vertices
+  // launch-bound graphs (nnz <= 2^18) only: the same rows with every row of more than kLatShortMax entries as a wave
+  // task (hg_plan_tune_f32 times it against the other kernels; the static rule never picks it)
+  hg::Sched sched_lat[2];
+  bool has_lat = false;
   std::map<int64_t, hg::FusedSched> fused;  // keyed by (slot, entry) capacity: depends on F
   std::map<int64_t, const hg::FusedSched *> fused_by_width;  // (F, vec4) -> the schedule built for it
   std::mutex fused_mu;
@@ -252,7 +257,7 @@ struct hg_plan {
   std::mutex stream_mu;
   int32_t stream_nslots[2] = {0, 0};  // partial rows a RowStream of each hop needs (independent of the lane layout)
   std::map<int64_t, int32_t> auto_choice;  // what HG_VARIANT_AUTO resolved to, keyed by (F, vec4)
-  std::map<int32_t, int32_t> hop_kernel;   // per F, set by hg_plan_tune_f32: bit h = pull hop h on the panel / task kernel
+  std::map<int32_t, int32_t> hop_kernel;   // per F, set by hg_plan_tune_f32: k0 + 3 * k1, kernel of each pull hop (hg_tune_info)
   std::mutex auto_mu;
   double small_nnz_frac = 0.0;  // share of incidences in hyperedges of <= t_big members
   int64_t device_bytes = 0;

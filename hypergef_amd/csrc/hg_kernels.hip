@@ -1231,18 +1231,18 @@ __global__ __launch_bounds__(256) void stream_rows_kernel(const StreamArgs a) {
 
 // Push form (the scheme the reference's group_* tensors describe, HyperGsys/balancer.py:15-33): a task sums the
 // member rows of one partition of a hyperedge and adds the scaled sum into the rows of Y that another partition
-// names, with memory-side fp32 atomics.  Here in this backend's lane layout: a row is spread over LPR lanes of VEC
-// floats (16-byte gathers where the width allows), a wave carries 64/LPR tasks, the source rows go eight at a time
-// into flight, and the scatter issues one global_atomic_add_f32 per float of the lane's piece.  Kept as the
-// drop-in for callers that bring the reference's schedule (any ngs, the w^2 task grid included) and as the CLI's
-// comparator; AUTO never picks it -- atomics run at about 1.3 TB/s of added bytes on this chip.
-template <int LPR, int VEC>
+// names, with memory-side fp32 atomics.  Lane layout: one feature column per lane, LPR = next_pow2(F) lanes per
+// task (64 / LPR tasks per wave) -- the shape the atomic units want: an atomic wave-instruction then covers whole
+// contiguous row segments (two 128-byte rows at F = 32), which is what runs at the chip's full atomic rate
+// (MI355X_MICROARCH.md, global float atomics); 16-byte lanes gather faster but scatter every fourth float per
+// instruction and lost 1.3-2x on the dataset shapes (profiles/r03_experiments.md).  The source rows go eight at a
+// time into flight.  Kept as the drop-in for callers that bring the reference's schedule (any ngs, the w^2 task
+// grid included) and as the CLI's comparator; AUTO never picks it -- atomics run at about 1.3 TB/s of added bytes.
+template <int LPR>
 __global__ __launch_bounds__(256) void push_tasks_kernel(const PushArgs a) {
-  using V = Vec<VEC>;
   constexpr int TPB = 256 / LPR, U = 8;
-  const int lane = threadIdx.x & (LPR - 1);
   const int64_t task = (int64_t)blockIdx.x * TPB + threadIdx.x / LPR;
-  const int col = (blockIdx.y * LPR + lane) * VEC;
+  const int col = blockIdx.y * LPR + (threadIdx.x & (LPR - 1));
   if (task >= a.n_group || col >= a.F) return;
   const int64_t F = a.F;
   // source partition, destination partition and hyperedge of this task: from the caller's schedule, or one task
@@ -1261,31 +1261,22 @@ __global__ __launch_bounds__(256) void push_tasks_kernel(const PushArgs a) {
     src_hi = dst_hi = a.csrptr_t[e + 1];
   }
   const float *xcol = a.X + col;
-  V sum = V::zero();
+  float sum = 0.f;
   for (int p = src_lo; p < src_hi; p += U) {  // members in order: the sum is the reference kernel's, bit for bit
-    V v[U];
+    float v[U];
 #pragma unroll
-    for (int j = 0; j < U; j++) {
-      const int q = min(p + j, src_hi - 1);
-      v[j] = V::loadu(xcol + (int64_t)a.colind_t[q] * F);
-    }
+    for (int j = 0; j < U; j++) v[j] = xcol[(int64_t)a.colind_t[min(p + j, src_hi - 1)] * F];
 #pragma unroll
     for (int j = 0; j < U; j++)
-      if (p + j < src_hi) sum.add(v[j]);
+      if (p + j < src_hi) sum += v[j];
   }
   float es = a.degE ? a.degE[e] : 1.f;  // degE * W first, then the sum times that product (hgnnaggr_cuda.cu:38)
   es *= a.W ? a.W[e] : 1.f;
-  sum.mul(es);
-  const int n = min(VEC, a.F - col);  // floats of this lane that exist
+  sum *= es;
+  float *ycol = a.Y + col;
   for (int p = dst_lo; p < dst_hi; p++) {
     const int64_t v = a.colind_t[p];
-    V out = sum;
-    if (a.degV) out.mul(a.degV[v]);
-    float *y = a.Y + v * F + col;
-    const float *o = reinterpret_cast<const float *>(&out);
-#pragma unroll
-    for (int j = 0; j < VEC; j++)
-      if (j < n) atomicAdd(y + j, o[j]);
+    atomicAdd(ycol + v * F, a.degV ? sum * a.degV[v] : sum);
   }
 }
 
@@ -1699,19 +1690,16 @@ int fused_tile_row_floats(int F, bool vec4) {
 }
 
 hipError_t launch_push(const PushArgs &a, hipStream_t stream) {
-  const bool vec4 = a.F % 4 == 0;  // dword-aligned 16-byte gathers (loadu: X may be only 4-byte aligned); other widths one float per lane
-  const int lanes = vec4 ? a.F / 4 : a.F;
-  const int lpr = std::min(64, next_pow2(std::max(lanes, 1)));
+  const int lpr = std::min(64, next_pow2(std::max(a.F, 1)));
   const int per_block = 256 / lpr;
-  const int tw = lpr * (vec4 ? 4 : 1);
-  const int col_tiles = (a.F + tw - 1) / tw;
+  const int col_tiles = (a.F + lpr - 1) / lpr;
   const int64_t nblocks = (a.n_group + per_block - 1) / per_block;
   if (nblocks == 0) return hipSuccess;
   if (nblocks > 0x7fffffffLL) return hipErrorInvalidValue;
-#define HG_CASE(L)                                                                                              \
-  case L:                                                                                                       \
-    if (vec4) hipLaunchKernelGGL((push_tasks_kernel<L, 4>), dim3((unsigned)nblocks, col_tiles), dim3(256), 0, stream, a); \
-    else hipLaunchKernelGGL((push_tasks_kernel<L, 1>), dim3((unsigned)nblocks, col_tiles), dim3(256), 0, stream, a);      \
+#define HG_CASE(L)                                                                              \
+  case L:                                                                                       \
+    hipLaunchKernelGGL((push_tasks_kernel<L>), dim3((unsigned)nblocks, col_tiles), dim3(256), 0, \
+                       stream, a);                                                              \
     break;
   switch (lpr) {
     HG_CASE(1)

@@ -126,7 +126,7 @@ class Plan:
 
     def tune(self, csrptr_t, colind_t, X, degE=None, degV=None, W=None, iters=20):
         """Timed choice of what variant="auto" runs for X's width (hg_plan_tune_f32): the fused schedule and the
-        pull variant with either kernel per hop are run `iters` times each on these tensors and the fastest is
+        pull variant with each of its kernels per hop (three on launch-bound graphs) are run `iters` times each on these tensors and the fastest is
         pinned -- the counterpart of the reference's tuner (HyperGAggr_tune, hgnnAgg.cuh:1115-1157), worth calling
         for a single dataset-sized hypergraph.  Returns {"variant", "pull_hop_kernels", "us": {...}}."""
         _check_feat(X, "node_feat")
@@ -144,7 +144,8 @@ class Plan:
         if hasattr(self, "_auto"):
             self._auto.pop(F, None)  # the cached answer of auto_variant may have changed
         names = {code: name for name, code in _lib.VARIANTS.items()}
-        labels = ("fused", "pull", "pull/hop0-panels", "pull/hop1-panels", "pull/panels")
+        kinds = ("stream", "panels", "tasks")  # per hop: streaming row gather, row panels + wave tasks, latency schedule
+        labels = ("fused", "pull") + tuple("pull/%s+%s" % (kinds[c % 3], kinds[c // 3]) for c in range(1, 9))
         return {"variant": names[info.variant], "pull_hop_kernels": info.pull_hop_kernels,
                 "us": {l: float(u) for l, u in zip(labels, info.us) if u >= 0}}
 

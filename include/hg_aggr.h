@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HG_AGGR_VERSION 201 /* major*10000 + minor*100 + patch */
+#define HG_AGGR_VERSION 300 /* major*10000 + minor*100 + patch */
 
 #if defined(__GNUC__)
 #define HG_API __attribute__((visibility("default")))
@@ -209,8 +209,12 @@ HG_API int hg_plan_auto_variant(const hg_plan *plan, int32_t F);
  * call it while other threads use the plan.  info may be NULL. */
 typedef struct hg_tune_info {
   int32_t variant;           /* HG_VARIANT_FUSED or HG_VARIANT_PULL */
-  int32_t pull_hop_kernels;  /* bit h set: pull hop h (0: vertices -> hyperedges) runs on the panel / task kernel */
-  float us[5];               /* microseconds per call: fused, pull with hop kernels 0 .. 3 (negative: not run) */
+  /* kernel of each pull hop (hop 0: vertices -> hyperedges), k0 + 3 * k1 with k = 0: streaming row gather,
+   * 1: row panels + wave tasks, 2 (graphs of at most 2^18 incidences): the same kernel on the latency schedule --
+   * every row of more than 8 entries is a wave task, its entries spread over the wave's lane groups and in
+   * flight at once, instead of a chain of dependent load batches in one lane group */
+  int32_t pull_hop_kernels;
+  float us[10];              /* microseconds per call: fused, pull with hop kernels 0 .. 8 (negative: not run) */
   int32_t reserved;
 } hg_tune_info;
 HG_API int hg_plan_tune_f32(const hg_plan *plan, int32_t F, const int32_t *csrptr_t, const int32_t *colind_t,

@@ -1040,6 +1040,62 @@ def test_options_are_per_call_and_follow_the_forward_into_backward(hg, oracle):
     assert torch.allclose(za, zb, rtol=1e-4, atol=1e-4) and ops.current_options() == ops.Options()
 
 
+def test_training_step_replays_as_a_hipgraph(hg):
+    """A whole training step of the 2-layer HGNN (forward through the fused aggregation + linear, nll loss,
+    backward through the library's aggregation / wgrad kernels, capturable Adam) recorded into one hipGraph:
+    K replays leave the parameters where K eager steps leave them (no dropout, deterministic kernels).  Nothing
+    in the library may allocate plan state, synchronise or read back during the captured step."""
+    import types
+    import torch.nn.functional as Fn
+    from hypergef_amd import models, plan as planmod
+    inc = _make("cora")
+    hyperg = hg.HyperGraph.from_incidence(inc, DEV, data_name="cora")
+    nfeat, nhid, ncls = 64, 32, 7
+    X = torch.randn(inc.N, nfeat, device=DEV, generator=torch.Generator(DEV).manual_seed(3))
+    y = torch.randint(0, ncls, (inc.N,), device=DEV, generator=torch.Generator(DEV).manual_seed(4))
+    idx = torch.arange(0, inc.N, 2, device=DEV)
+    args = types.SimpleNamespace(model="HGNN", activation="relu", input_drop=0.0, dropout=0.0, backend="hgsys")
+
+    def make():
+        torch.manual_seed(11)
+        m = models.HGsysHGNN(args, hyperg, nfeat, nhid, ncls, 2, "sum", 1).to(DEV).train()
+        return m, torch.optim.Adam(m.parameters(), lr=0.01, weight_decay=5e-4, capturable=True)
+
+    def step(m, o):
+        o.zero_grad(set_to_none=True)
+        loss = Fn.nll_loss(m(X)[idx], y[idx])
+        loss.backward()
+        o.step()
+        return loss.detach()
+
+    warm, K = 3, 6
+    ma, oa = make()
+    for _ in range(warm + K):
+        la = step(ma, oa)
+    mb, ob = make()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(warm):
+            step(mb, ob)
+    torch.cuda.current_stream().wait_stream(side)
+    planmod.clear_pack_cache()  # cached packings are keyed on version counters a replay does not advance
+    g = torch.cuda.CUDAGraph()
+    ob.zero_grad(set_to_none=True)
+    with torch.cuda.graph(g):
+        lb = Fn.nll_loss(mb(X)[idx], y[idx])
+        lb.backward()
+        ob.step()
+    planmod.clear_pack_cache()
+    for _ in range(K):
+        g.replay()
+    torch.cuda.synchronize()
+    for pa, pb in zip(ma.parameters(), mb.parameters()):
+        assert torch.allclose(pa, pb, rtol=1e-5, atol=1e-6), float((pa - pb).abs().max())
+    assert abs(float(la) - float(lb)) <= 1e-5 * max(1.0, abs(float(la)))
+    planmod.clear_pack_cache()
+
+
 def test_rccl_branches_execute_at_world_size_one(hg, tmp_path):
     """The `nccl` (= RCCL) branches of hypergef_amd.dist on the one GPU there is: a child process initialises a
     one-rank RCCL process group before touching the GPU and runs every exchange form with force_collective=True
@@ -1344,7 +1400,8 @@ def test_timed_choice_pins_auto_and_keeps_results(hg, oracle, dname):
     plan = Plan.from_tensors(inc.N, ptr, ind)
     before = plan.auto_variant(F)
     info = plan.tune(ptr, ind, Xd, iters=10)
-    assert info["variant"] in ("fused", "pull") and 0 <= info["pull_hop_kernels"] <= 3
+    assert info["variant"] in ("fused", "pull") and 0 <= info["pull_hop_kernels"] <= 8
+    assert len(info["us"]) == 10  # launch-bound graphs: the latency schedule's candidates ran too
     assert "pull" in info["us"] and len(info["us"]) >= 4 and all(u > 0 for u in info["us"].values())
     assert plan.auto_variant(F) == info["variant"], (before, info)
     best = min(info["us"], key=info["us"].get)

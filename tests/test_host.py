@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol(hg):
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.hg_version() == 201  # HG_AGGR_VERSION: round 2 changed hg_plan_opts and hg_fused_info
+    assert L.hg_version() == 300  # HG_AGGR_VERSION: round 3 changed hg_tune_info
     assert L.hg_status_string(-4) == b"workspace too small"
 
 

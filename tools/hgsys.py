@@ -107,7 +107,10 @@ def main():
         loss = F.nll_loss(Z[train_idx], y[train_idx])
         loss.backward()
         opti.step()
-        return loss
+        # detached: a loss that keeps its graph alive also keeps the parameters' AccumulateGrad nodes alive, with
+        # the stream they were created on -- a later capture on another stream would then accumulate gradients on
+        # that (non-capturing) stream and the capture breaks
+        return loss.detach()
 
     for _ in range(10):
         loss = train_epoch()
