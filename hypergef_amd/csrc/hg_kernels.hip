@@ -393,6 +393,26 @@ __device__ __forceinline__ void load_bfrag(const float *wfrag, int nt, int lane,
   }
 }
 
+// K = 128 (32 k-steps): holding all 32 B-fragment registers of a column tile through the matrix phase is what kept the
+// LIN instances at 5 waves per SIMD.  There the fragments travel in chunks of 8 k-steps (two dwordx4 per lane), the
+// next chunk in flight while the current one feeds the matrix pipe.  BPre<KSTEPS>::N = fragments the caller preloads.
+template <int KSTEPS> struct BPre {
+  static constexpr int CH = KSTEPS >= 32 ? 8 : KSTEPS;  // k-steps per chunk
+  static constexpr int N = CH;
+};
+template <int KSTEPS>
+__device__ __forceinline__ void load_bfrag_chunk(const float *wfrag, int nt, int chunk, int lane, float (&b)[8]) {
+  const float4 *w = reinterpret_cast<const float4 *>(wfrag) + ((int64_t)nt * (KSTEPS / 4) + 2 * chunk) * 64 + lane;
+  const float4 f0 = w[0], f1 = w[64];
+  b[0] = f0.x; b[1] = f0.y; b[2] = f0.z; b[3] = f0.w;
+  b[4] = f1.x; b[5] = f1.y; b[6] = f1.z; b[7] = f1.w;
+}
+template <int KSTEPS>
+__device__ __forceinline__ void load_bfrag_pre(const float *wfrag, int nt, int lane, float (&b)[BPre<KSTEPS>::N]) {
+  if constexpr (KSTEPS >= 32) load_bfrag_chunk<KSTEPS>(wfrag, nt, 0, lane, b);
+  else load_bfrag<KSTEPS>(wfrag, nt, lane, b);
+}
+
 __global__ __launch_bounds__(256) void linear_pack_kernel(int32_t F_out, int32_t F_in, const float *Wlin,
                                                           float *wfrag) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -508,39 +528,187 @@ __device__ __forceinline__ void panel_times_wt_staged(float *t, int nrows, int F
   }
 }
 
-template <int KSTEPS>
+// The matrix phase for K = 128: B fragments in chunks of 8 k-steps, double-buffered (16 registers instead of 32 per
+// column tile), the A-fragment reads two k-steps ahead of their MFMAs as in mfma_rows.  NRT row tiles (compile time)
+// against the wave's NPW column tiles; acc[ni * RPN + j].
+template <int KSTEPS, int NPW, int NRT>
+__device__ __forceinline__ void mfma_rows_chunked(const float *ta, int tstep, const float *Wlin, const LinSplit &sp, int NT,
+                                                  int lane, const float (&bpre)[8], hg_f4 *acc) {
+  constexpr int RPN = 4 / NPW, CH = 8, NCH = KSTEPS / CH;
+  float bcur[8], bnxt[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) bcur[i] = bpre[i];
+#pragma unroll
+  for (int ni = 0; ni < NPW; ni++) {
+    const int nt = sp.nt_first + ni * sp.nt_step;
+    if (nt < NT) {  // wave-uniform
+      float a0[NRT], a1[NRT], a2[NRT];
+#pragma unroll
+      for (int j = 0; j < NRT; j++) {
+        a0[j] = ta[j * tstep];
+        a1[j] = ta[j * tstep + 4];
+      }
+#pragma unroll
+      for (int c = 0; c < NCH; c++) {
+        // the next chunk's fragments (this column tile's, or chunk 0 of the wave's next tile) fly during this one's MFMAs
+        const int nt2 = sp.nt_first + (ni + 1) * sp.nt_step;
+        if (c + 1 < NCH) load_bfrag_chunk<KSTEPS>(Wlin, nt, c + 1, lane, bnxt);
+        else if (ni + 1 < NPW && nt2 < NT) load_bfrag_chunk<KSTEPS>(Wlin, nt2, 0, lane, bnxt);
+#pragma unroll
+        for (int k8 = 0; k8 < CH; k8++) {
+          const int ks = c * CH + k8;
+          if (ks + 2 < KSTEPS) {
+#pragma unroll
+            for (int j = 0; j < NRT; j++) a2[j] = ta[j * tstep + (ks + 2) * 4];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < NRT; j++)
+            acc[ni * RPN + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], bcur[k8], acc[ni * RPN + j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < NRT; j++) {
+            a0[j] = a1[j];
+            a1[j] = a2[j];
+          }
+        }
+        if (c + 1 < NCH || (ni + 1 < NPW && nt2 < NT)) {
+#pragma unroll
+          for (int i = 0; i < 8; i++) bcur[i] = bnxt[i];
+        }
+      }
+    }
+  }
+}
+
+// The staged form (see panel_times_wt_staged) on the chunked matrix phase.  bpre: chunk 0 of the wave's first column
+// tile, loaded by the caller ahead of the barriers.
+template <int KSTEPS, int NPW>
+__device__ __forceinline__ void panel_times_wt_staged_chunked(float *t, int nrows, int F_out, const float *Wlin,
+                                                              const int32_t *rowmap, int64_t row0, float *Y, int tid,
+                                                              float (&bpre)[8], int relu) {
+  constexpr int K = KSTEPS * 4, LD = K + 4, RPN = 4 / NPW;
+  const int lane = tid & 63;
+  const int NT = F_out >> 4, RT = (nrows + 15) >> 4;
+  const LinSplit sp = lin_split(tid >> 6, NT);
+  hg_f4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) acc[j] = hg_f4{0.f, 0.f, 0.f, 0.f};
+  int nrt = 0;
+  if (sp.active) {
+    nrt = min(RPN, max(0, (RT - sp.rt_first + sp.rt_step - 1) / sp.rt_step));
+    const float *ta = t + (sp.rt_first * 16 + (lane & 15)) * LD + (lane >> 4);
+    const int tstep = sp.rt_step * 16 * LD;
+    switch (nrt) {  // wave-uniform
+      case 4: if constexpr (RPN >= 4) mfma_rows_chunked<KSTEPS, NPW, 4>(ta, tstep, Wlin, sp, NT, lane, bpre, acc); break;
+      case 3: if constexpr (RPN >= 4) mfma_rows_chunked<KSTEPS, NPW, 3>(ta, tstep, Wlin, sp, NT, lane, bpre, acc); break;
+      case 2: if constexpr (RPN >= 2) mfma_rows_chunked<KSTEPS, NPW, 2>(ta, tstep, Wlin, sp, NT, lane, bpre, acc); break;
+      case 1: mfma_rows_chunked<KSTEPS, NPW, 1>(ta, tstep, Wlin, sp, NT, lane, bpre, acc); break;
+      default: break;
+    }
+  }
+  __syncthreads();  // every wave has read its A fragments: the rows can be overwritten
+  if (sp.active) {
+#pragma unroll
+    for (int ni = 0; ni < NPW; ni++) {
+      const int nt = sp.nt_first + ni * sp.nt_step;
+      if (nt < NT) {
+#pragma unroll
+        for (int j = 0; j < RPN; j++)
+          if (j < nrt) {
+            float *d = t + ((sp.rt_first + j * sp.rt_step) * 16 + 4 * (lane >> 4)) * LD + nt * 16 + (lane & 15);
+#pragma unroll
+            for (int i = 0; i < 4; i++) d[i * LD] = acc[ni * RPN + j][i];
+          }
+      }
+    }
+  }
+  __syncthreads();
+  const int q = F_out >> 2;  // float4 pieces per row
+  for (int i = tid; i < nrows * q; i += 256) {
+    const int r = i / q, c = (i - r * q) * 4;
+    const int64_t yrow = rowmap ? (int64_t)rowmap[r] : row0 + r;
+    float4 o = *reinterpret_cast<const float4 *>(t + r * LD + c);
+    if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+    if (HG_Y_NT) Vec<4>{o}.store_nt(Y + yrow * F_out + c);
+    else *reinterpret_cast<float4 *>(Y + yrow * F_out + c) = o;
+  }
+}
+
+// WIDE = false: the caller guarantees the staged form applies (F_out <= K and few enough row tiles); the direct form
+// for wider outputs is then not compiled in -- its registers would set the budget of the whole kernel.
+template <int KSTEPS, bool WIDE = true>
 __device__ __forceinline__ void panel_times_wt(float *t, int nrows, int F_out, const float *Wlin,
                                                const int32_t *rowmap, int64_t row0, float *Y, int tid,
-                                               float (&bv)[KSTEPS], int relu) {
+                                               float (&bpre)[BPre<KSTEPS>::N], int relu) {
   constexpr int K = KSTEPS * 4, LD = K + 4;
   const int nt_all = F_out >> 4, nwr = nt_all >= 3 ? 1 : 4 / nt_all;  // as lin_split
   const int rt_per_wave = (((nrows + 15) >> 4) + nwr - 1) / nwr;
-  if (F_out <= K && rt_per_wave <= (F_out > 64 ? 2 : 4)) {  // workgroup-uniform
-    if (F_out > 64) panel_times_wt_staged<KSTEPS, 2>(t, nrows, F_out, Wlin, rowmap, row0, Y, tid, bv, relu);
-    else panel_times_wt_staged<KSTEPS, 1>(t, nrows, F_out, Wlin, rowmap, row0, Y, tid, bv, relu);
+  if (!WIDE || (F_out <= K && rt_per_wave <= (F_out > 64 ? 2 : 4))) {  // workgroup-uniform
+    if constexpr (KSTEPS >= 32) {
+      if (F_out > 64) panel_times_wt_staged_chunked<KSTEPS, 2>(t, nrows, F_out, Wlin, rowmap, row0, Y, tid, bpre, relu);
+      else panel_times_wt_staged_chunked<KSTEPS, 1>(t, nrows, F_out, Wlin, rowmap, row0, Y, tid, bpre, relu);
+    } else {
+      if (F_out > 64) panel_times_wt_staged<KSTEPS, 2>(t, nrows, F_out, Wlin, rowmap, row0, Y, tid, bpre, relu);
+      else panel_times_wt_staged<KSTEPS, 1>(t, nrows, F_out, Wlin, rowmap, row0, Y, tid, bpre, relu);
+    }
     return;
   }
+  if constexpr (!WIDE) return;
   // wider output than input: results go straight to Y, 64 bytes per row and instruction
   const int lane = tid & 63;
   const int NT = F_out >> 4, RT = (nrows + 15) >> 4;
   const LinSplit sp = lin_split(tid >> 6, NT);
   if (!sp.active) return;
-  for (int nt = sp.nt_first; nt < NT; nt += sp.nt_step) {
-    if (nt != sp.nt_first) load_bfrag<KSTEPS>(Wlin, nt, lane, bv);
+  auto store_tiles = [&](int nt, int rt, int n, const hg_f4 *acc) {
     float *ycol = Y + nt * 16 + (lane & 15);
-    for (int rt = sp.rt_first; rt < RT; rt += 4 * sp.rt_step) {
-      const int n = min(4, (RT - rt + sp.rt_step - 1) / sp.rt_step);  // wave-uniform
-      hg_f4 acc[4];
-      mfma_rows_n<KSTEPS>(n, t, LD, rt, sp.rt_step, bv, acc, lane);
 #pragma unroll
-      for (int j = 0; j < 4; j++)
-        if (j < n) {
+    for (int j = 0; j < 4; j++)
+      if (j < n) {
 #pragma unroll
-          for (int i = 0; i < 4; i++) {
-            const int r = (rt + j * sp.rt_step) * 16 + 4 * (lane >> 4) + i;
-            if (r < nrows) ycol[(rowmap ? (int64_t)rowmap[r] : row0 + r) * F_out] = relu ? fmaxf(acc[j][i], 0.f) : acc[j][i];
-          }
+        for (int i = 0; i < 4; i++) {
+          const int r = (rt + j * sp.rt_step) * 16 + 4 * (lane >> 4) + i;
+          if (r < nrows) ycol[(rowmap ? (int64_t)rowmap[r] : row0 + r) * F_out] = relu ? fmaxf(acc[j][i], 0.f) : acc[j][i];
         }
+      }
+  };
+  if constexpr (KSTEPS >= 32) {  // K = 128: the chunked matrix phase here too (32 fragment registers would set the kernel's budget)
+    for (int nt = sp.nt_first; nt < NT; nt += sp.nt_step) {
+      float b0[8];
+      if (nt == sp.nt_first) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) b0[i] = bpre[i];
+      } else {
+        load_bfrag_chunk<KSTEPS>(Wlin, nt, 0, lane, b0);
+      }
+      LinSplit one = sp;
+      one.nt_first = nt;
+      for (int rt = sp.rt_first; rt < RT; rt += 2 * sp.rt_step) {  // two row tiles at a time: the register budget of the staged form
+        const int n = min(2, (RT - rt + sp.rt_step - 1) / sp.rt_step);  // wave-uniform
+        hg_f4 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[j] = hg_f4{0.f, 0.f, 0.f, 0.f};
+        const float *ta = t + (rt * 16 + (lane & 15)) * LD + (lane >> 4);
+        const int tstep = sp.rt_step * 16 * LD;
+        if (n == 2) mfma_rows_chunked<KSTEPS, 1, 2>(ta, tstep, Wlin, one, NT, lane, b0, acc);
+        else mfma_rows_chunked<KSTEPS, 1, 1>(ta, tstep, Wlin, one, NT, lane, b0, acc);
+        store_tiles(nt, rt, n, acc);
+      }
+    }
+  } else {
+    float bv[KSTEPS];
+    for (int nt = sp.nt_first; nt < NT; nt += sp.nt_step) {
+      if (nt != sp.nt_first) load_bfrag<KSTEPS>(Wlin, nt, lane, bv);
+      else {
+#pragma unroll
+        for (int i = 0; i < KSTEPS; i++) bv[i] = bpre[i];
+      }
+      for (int rt = sp.rt_first; rt < RT; rt += 4 * sp.rt_step) {
+        const int n = min(4, (RT - rt + sp.rt_step - 1) / sp.rt_step);  // wave-uniform
+        hg_f4 acc[4];
+        mfma_rows_n<KSTEPS>(n, t, LD, rt, sp.rt_step, bv, acc, lane);
+        store_tiles(nt, rt, n, acc);
+      }
     }
   }
 }
@@ -557,9 +725,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KSTEPS >= 3
   __shared__ float t[R * LD];
   const int64_t row0 = (int64_t)blockIdx.x * R;
   const int nrows = (int)min((int64_t)R, a.nrows - row0);
-  float bv[KSTEPS];
+  float bv[BPre<KSTEPS>::N];
   const LinSplit sp = lin_split(threadIdx.x >> 6, a.F_out >> 4);
-  if (sp.active) load_bfrag<KSTEPS>(a.Wlin, sp.nt_first, threadIdx.x & 63, bv);
+  if (sp.active) load_bfrag_pre<KSTEPS>(a.Wlin, sp.nt_first, threadIdx.x & 63, bv);
   constexpr int NL = R * (K / 4) / 256;  // float4 loads per thread, all in flight before the first LDS write
   float4 v[NL];
 #pragma unroll
@@ -701,6 +869,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *partial,
 #ifndef HG_LIN_WAVES32
 #define HG_LIN_WAVES32 5
 #endif
+#ifndef HG_LIN_WAVES_STAGED
+#define HG_LIN_WAVES_STAGED 8
+#endif
 typedef unsigned hg_u4 __attribute__((ext_vector_type(4)));
 typedef int hg_i4 __attribute__((ext_vector_type(4)));
 
@@ -714,9 +885,16 @@ typedef int hg_i4 __attribute__((ext_vector_type(4)));
 // the ablation switches (a.debug) in the code; production instances have none.
 // LIN: the rows a panel produces go through panel_times_wt (Y = rows * Wlin^T, F_out columns)
 // instead of straight to Y; needs F == LPR * VEC and at most 4 rows per lane group.
-template <int LPR, int VEC, int U, bool FAST, bool MAT, bool SCALED, bool DBG, bool LIN = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LIN ? (LPR >= 32 ? HG_LIN_WAVES32 : LPR == 16 ? HG_LIN_WAVES16 : HG_LIN_WAVES8) : 1, 8))) void fused_packed_kernel(const FusedArgs a) {
-  constexpr int BS = 256;
+// BS: threads per panel workgroup.  Only 256 is instantiated: 512- / 1024-thread workgroups with two / four times the
+// tile (the panel shape of F = 32 for rows of 64 and 128 floats, same waves and LDS per CU) were 3-9 % slower on every
+// wide-row batch (profiles/r03_experiments.md).
+// LINW (LIN only): the output may be wider than the input, or a panel hold more row tiles than the staged matrix phase
+// takes -- the direct form is compiled in.  LINW = false instances (F_out <= F, the common case) carry the staged form
+// only and fit 8 waves per SIMD without spills; the direct form's registers used to set the budget of every LIN
+// instance (natural demand 85-92 VGPRs, 5-6 waves).
+template <int LPR, int VEC, int U, bool FAST, bool MAT, bool SCALED, bool DBG, bool LIN = false, int BS = 256, bool LINW = true>
+__global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW ? HG_LIN_WAVES_STAGED : LPR >= 32 ? HG_LIN_WAVES32 : LPR == 16 ? HG_LIN_WAVES16 : HG_LIN_WAVES8) : 1, 8))) void fused_packed_kernel(const FusedArgs a) {
+  static_assert(!LIN || BS == 256, "the linear epilogue is written for four waves");
   constexpr int NG = BS / LPR;
   constexpr int TW = LPR * VEC;
   using V = Vec<VEC>;
@@ -882,9 +1060,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LIN ? (LPR 
     }
     // the B fragments of this wave's first column tile: in flight across the two barriers below
     // (issued before hop 2 they would hold K/4 more registers through it: 78 instead of 64 VGPRs)
-    float bv[TW / 4];
+    float bv[BPre<TW / 4>::N];
     const LinSplit sp = lin_split(tid >> 6, a.F_out >> 4);
-    if (sp.active && !(DBG && (a.debug & 512))) load_bfrag<TW / 4>(a.Wlin, sp.nt_first, tid & 63, bv);
+    if (sp.active && !(DBG && (a.debug & 512))) load_bfrag_pre<TW / 4>(a.Wlin, sp.nt_first, tid & 63, bv);
     __syncthreads();  // every slot row has been read: the tile becomes the [rows][TW + 4] operand
 #pragma unroll
     for (int i = 0; i < 4; i++)
@@ -907,7 +1085,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LIN ? (LPR 
             *reinterpret_cast<const float4 *>(tile + r * (TW + 4) + c);
       }
     }
-    panel_times_wt<TW / 4>(tile, nrows, a.F_out, a.Wlin, prow, 0, a.Y, tid, bv, a.epi.relu);
+    panel_times_wt<TW / 4, LINW>(tile, nrows, a.F_out, a.Wlin, prow, 0, a.Y, tid, bv, a.epi.relu);
   } else if (!(DBG && (a.debug & 8))) {  // ---- hop 2
     const int rpg = (nrows + NG - 1) / NG;
     const int r0 = min(g * rpg, nrows), r1 = min(r0 + rpg, nrows);
@@ -1504,8 +1682,8 @@ hipError_t launch_hub_pass(const HubArgs &a0, bool vec4, hipStream_t stream) {
 template <int LPR, int VEC>
 static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
   if (a.npanels == 0) return hipSuccess;
-  if (a.ng != 256 / LPR) return hipErrorInvalidValue;  // records were packed for another lane layout
   constexpr int TW = LPR * VEC;
+  if (a.ng != 256 / LPR) return hipErrorInvalidValue;  // records were packed for another lane layout
   const int col_tiles = (a.F + TW - 1) / TW;
   const Tuning &t = tuning();
   FusedArgs ad = a;
@@ -1523,7 +1701,12 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
         if (!fast || a.F != TW || a.rows_cap > 4 * (256 / LPR) || (a.F_out & 15)) return hipErrorInvalidValue;
         const size_t lds_l = lds_p + (size_t)a.cap * 4 * 4;  // + 4 pad floats per tile row
         const int spec = (a.Xe_mat ? 1 : 0) | ((a.degE || a.W) ? 2 : 0);
-#define HG_PKL(M, S) return launch_lds<fused_packed_kernel<LPR, VEC, 8, true, M, S, false, true>>(grid, lds_l, stream, ad)
+        // the staged matrix phase alone serves this call (as panel_times_wt decides per panel, for the fullest panel)
+        const int nt_all = a.F_out >> 4, nwr = nt_all >= 3 ? 1 : 4 / nt_all;
+        const bool staged = a.F_out <= TW && (((a.rows_cap + 15) >> 4) + nwr - 1) / nwr <= (a.F_out > 64 ? 2 : 4);
+#define HG_PKL(M, S)                                                                                                          \
+  return staged ? launch_lds<fused_packed_kernel<LPR, VEC, 8, true, M, S, false, true, 256, false>>(grid, lds_l, stream, ad) \
+                : launch_lds<fused_packed_kernel<LPR, VEC, 8, true, M, S, false, true, 256, true>>(grid, lds_l, stream, ad)
 #ifdef HG_TUNING
         if (t.fused_debug & 768)  // ablations of the matrix phase (tools/linear_probe.py): diagnostic build only
           return launch_lds<fused_packed_kernel<LPR, VEC, 8, true, true, true, true, true>>(grid, lds_l, stream, ad);
