@@ -438,6 +438,10 @@ int run_hop(const hg_plan *p, int hop, int32_t F, const int32_t *ptr, const int3
   // kernel loads through a range-checked descriptor and stores only the columns that exist
   const bool lanes16 = F % 4 == 0 || F > 8;
   const int64_t nsrc = hop == 0 ? p->N : p->M, sb = nsrc * F * 4;
+  // Streaming (nt) stores for the hop's output: always for hop 2 (rows of Y); for hop 1 when Xe [M, F] is larger than
+  // the 256 MiB Infinity Cache -- a smaller table is read straight back from it by hop 2 and plain stores keep it
+  // there (same-box A/B, profiles/r03_experiments.md: 348-695 MB tables -3..-6 %, 2-143 MB tables +9..+16 % with nt)
+  const bool nt_out = hop == 1 || (int64_t)p->M * F * 4 >= ((int64_t)256 << 20);
   int kind = 0;  // hg_plan_tune_f32's choice for this hop and width: 0 streaming, 1 panels + tasks, 2 latency schedule
   {
     hg_plan *mp = const_cast<hg_plan *>(p);
@@ -466,19 +470,19 @@ int run_hop(const hg_plan *p, int hop, int32_t F, const int32_t *ptr, const int3
     sa.partial = partial;
     sa.F = F;
     sa.xcd_remap = (p->opts.flags & HG_PLAN_NO_XCD_REMAP) ? 0 : 1;
-    sa.nt_dst = hop == 1;  // hop 2 writes Y; hop 1's Xe is read straight back
+    sa.nt_dst = nt_out;
     if (sa.nrec == 0) return HG_OK;
     if (hg::stream_rows_ok(sa, true)) {
       hipError_t e = hg::launch_stream_rows(sa, stream);
       if (e == hipSuccess)
         e = hg::launch_fixups(rs->d_fixups, (int)rs->fixups.size(), rs->n_fix_l1, F, partial, dst, scaleA, scaleB,
-                              nullptr, true, stream, hop == 1);
+                              nullptr, true, stream, nt_out);
       if (e != hipSuccess) return hip_fail("stream_rows launch", e);
       return HG_OK;
     }
   }
   return run_sched(p, (kind == 2 && p->has_lat) ? p->sched_lat[hop] : p->sched[hop], F, ptr, ind, src, scaleA, scaleB,
-                   nullptr, nullptr, dst, partial, stream, hop == 1);
+                   nullptr, nullptr, dst, partial, stream, nt_out);
 }
 
 // pull_only: the call runs the pull layout whatever schedules exist (a forced HG_VARIANT_PULL, a single hop): a
