@@ -439,9 +439,9 @@ int run_hop(const hg_plan *p, int hop, int32_t F, const int32_t *ptr, const int3
   const bool lanes16 = F % 4 == 0 || F > 8;
   const int64_t nsrc = hop == 0 ? p->N : p->M, sb = nsrc * F * 4;
   // Streaming (nt) stores for the hop's output: always for hop 2 (rows of Y); for hop 1 when Xe [M, F] is larger than
-  // the 256 MiB Infinity Cache -- a smaller table is read straight back from it by hop 2 and plain stores keep it
+  // about three quarters of the 256 MiB Infinity Cache -- a smaller table is read straight back from it by hop 2 and plain stores keep it
   // there (same-box A/B, profiles/r03_experiments.md: 348-695 MB tables -3..-6 %, 2-143 MB tables +9..+16 % with nt)
-  const bool nt_out = hop == 1 || (int64_t)p->M * F * 4 >= ((int64_t)256 << 20);
+  const bool nt_out = hop == 1 || (int64_t)p->M * F * 4 >= ((int64_t)192 << 20);
   int kind = 0;  // hg_plan_tune_f32's choice for this hop and width: 0 streaming, 1 panels + tasks, 2 latency schedule
   {
     hg_plan *mp = const_cast<hg_plan *>(p);
