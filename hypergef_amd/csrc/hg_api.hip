@@ -147,20 +147,13 @@ bool wide_rows_ok(const hg_plan *p, int32_t F) {
 }
 bool plan_vec4(const hg_plan *p, int32_t F) { return F % 4 == 0 || wide_rows_ok(p, F); }
 
-// Threads per panel workgroup for width F: the caller's fused_block where the kernels have that instance (16-byte
-// lanes, 16 or 32 lanes per row: F = 64 .. 128 in multiples of 4), else 256.
-int32_t fused_block_for(const hg_plan *p, int32_t F, bool vec4) {
-  const int32_t lanes = hg::fused_tile_row_floats(F, vec4) / (vec4 ? 4 : 1);
-  return (vec4 && F % 4 == 0 && (lanes == 16 || lanes == 32) && wide_rows_ok(p, F)) ? p->opts.fused_block : 256;
-}
-
 void fused_caps(const hg_plan *p, int32_t F, bool vec4, int32_t &cap, int32_t &mem_cap, int32_t tile_bytes = 0) {
   const int row_bytes = hg::fused_tile_row_floats(F, vec4) * 4;
   const int c = std::max(16, std::min(256, (tile_bytes > 0 ? tile_bytes : p->opts.fused_tile_bytes) / row_bytes));
   cap = c / 16 * 16;
   mem_cap = cap * 4;
   if (p->opts.fused_steps > 0) {  // whole batches of the kernel's row loads: steps x lane groups
-    const int32_t ng = fused_block_for(p, F, vec4) / (hg::fused_tile_row_floats(F, vec4) / (vec4 ? 4 : 1));
+    const int32_t ng = 256 / (hg::fused_tile_row_floats(F, vec4) / (vec4 ? 4 : 1));
     mem_cap = std::max(p->opts.t_big, std::min(mem_cap, p->opts.fused_steps * ng));
   }
 }
@@ -183,8 +176,7 @@ int get_fused(const hg_plan *cp, int32_t F, bool vec4, const hg::FusedSched **ou
   int32_t cap, mem_cap;
   fused_caps(p, F, vec4, cap, mem_cap);
   const int32_t row_floats = hg::fused_tile_row_floats(F, vec4);
-  const int32_t ng256 = 256 / (row_floats / (vec4 ? 4 : 1));  // lane groups of a 256-thread workgroup
-  const int32_t ng = ng256 * (fused_block_for(p, F, vec4) / 256);  // lane groups of a panel workgroup
+  const int32_t ng = 256 / (row_floats / (vec4 ? 4 : 1));  // lane groups per workgroup
   // The hub pass reads X and the materialised table through buffer descriptors (row index below 2^24,
   // tables below 2 GiB) and exists for 16-byte lanes of at least 16 floats per row.
   // (rows of the materialised table are masked to 24 bits in the round records too, and n_mat <= M)
@@ -197,7 +189,7 @@ int get_fused(const hg_plan *cp, int32_t F, bool vec4, const hg::FusedSched **ou
     hg::FusedSched f;
     try {
       hg::build_fused(p->N, p->M, p->ptr_t.data(), p->ind_t.data(), p->ptr_v.data(), p->ind_v.data(),
-                      p->opts, cap, mem_cap, ng, row_floats, allow_hub, f, ng256);
+                      p->opts, cap, mem_cap, ng, row_floats, allow_hub, f);
       // A small hypergraph is launch-bound (small_graph_cost).  Two things can shorten it: recomputing the
       // few longish hyperedges too instead of a materialisation launch (one citeseer-shape hypergraph
       // 15.8 -> 8.2 us at F = 32), and -- unless the caller fixed the tile -- smaller panels: more, shorter
@@ -224,7 +216,7 @@ int get_fused(const hg_plan *cp, int32_t F, bool vec4, const hg::FusedSched **ou
             }
             hg::FusedSched alt;
             hg::build_fused(p->N, p->M, p->ptr_t.data(), p->ind_t.data(), p->ptr_v.data(), p->ind_v.data(), o, c2, m2,
-                            ng, row_floats, allow_hub, alt, ng256);
+                            ng, row_floats, allow_hub, alt);
             if (alt.invalid) continue;
             const double c = small_graph_cost(alt);
             if (c < best) {

@@ -129,8 +129,7 @@ static void pack_stream(const std::vector<SlotRange> &slots, const int32_t *mem,
 
 void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_t,
                  const int32_t *ptr_v, const int32_t *ind_v, const Opts &o, int32_t cap,
-                 int32_t mem_cap, int32_t ng, int32_t row_floats, bool allow_hub, FusedSched &f, int32_t ng256) {
-  if (ng256 <= 0) ng256 = ng;
+                 int32_t mem_cap, int32_t ng, int32_t row_floats, bool allow_hub, FusedSched &f) {
   f = FusedSched();
   f.cap = cap;
   f.rows_cap = cap;
@@ -157,7 +156,7 @@ void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_
       f.mat_ptr.push_back((int32_t)f.mat_ind.size());
     }
   build_sched(f.n_mat, f.mat_ptr.data(), o, f.mat_sched);
-  if (allow_hub) build_row_stream(f.n_mat, f.mat_ptr.data(), f.mat_ind.data(), f.mat_eid.data(), ng256, N, f.mat_stream);
+  if (allow_hub) build_row_stream(f.n_mat, f.mat_ptr.data(), f.mat_ind.data(), f.mat_eid.data(), ng, N, f.mat_stream);
 
   // ---- vertices that do not fit a panel: register hubs, or pieces ------------------------------
   // big[v]: 1 = register hub, 2 = split into pieces
@@ -180,7 +179,7 @@ void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_
   }
   std::vector<int32_t> hub_of((size_t)N, -1), parts;
   HubPass &hp = f.hub;
-  hub_geometry(ng256, row_floats, o.hub_tile_bytes, hp);
+  hub_geometry(ng, row_floats, o.hub_tile_bytes, hp);
   const int32_t kHubMinDeg = o.hub_min_deg;
   // one hyperedge of t_big members and a pair for every hub must fit an empty round's record
   allow_hub = allow_hub && hub_rec_bound(hp, f.t_big, f.t_big, 1, hp.ng * hp.R) <= kHubRecWords;

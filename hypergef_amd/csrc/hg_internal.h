@@ -202,7 +202,6 @@ struct Opts {
   // whole keep their summation order.
   int32_t slot_chunk = 0;
   int32_t fused_steps = 0;           // fused: stream entries per lane group and panel (0: 4 per slot on average)
-  int32_t fused_block = 256;         // fused: threads per panel workgroup (256 | 512 | 1024)
   // hub pass (not in the C ABI; the host tests lower them to reach that code on small graphs)
   int64_t hub_min_nnz = 1 << 20;  // smaller graphs are launch-bound: no extra pass
   int32_t hub_min_deg = 256;      // below this a hub's partial rows cost more than pieces do
@@ -225,11 +224,9 @@ void classify_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *p
                     const Opts &o, int32_t cap, int32_t mem_cap, int64_t *n_mat, int64_t *n_big);
 // row_floats: floats per LDS tile row (the kernels' TW); allow_hub: the hub pass may be used
 // (buffer-addressable tables).
-// ng: lane groups of a panel workgroup (fused_block / lanes per row); ng256: lane groups of a 256-thread workgroup
-// with the same lanes per row (what the streaming row gather and the hub pass are built around)
 void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_t,
                  const int32_t *ptr_v, const int32_t *ind_v, const Opts &o, int32_t cap,
-                 int32_t mem_cap, int32_t ng, int32_t row_floats, bool allow_hub, FusedSched &f, int32_t ng256 = 0);
+                 int32_t mem_cap, int32_t ng, int32_t row_floats, bool allow_hub, FusedSched &f);
 // rows [0, nrows) of the CSR (ptr, ind) as a RowStream; scale_index[r] (or r itself if null) names the
 // row's scale factors; idle = rows of the gathered table
 void build_row_stream(int32_t nrows, const int32_t *ptr, const int32_t *ind, const int32_t *scale_index,
