@@ -27,6 +27,8 @@ int hip_fail(const char *what, hipError_t e) {
 size_t round256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+// rows of an output table are whole, aligned 64-byte units: where the streaming (nt) store hint pays (hg_kernels.hip, HG_Y_NT)
+bool rows_whole_64(const void *base, int32_t F) { return F % 16 == 0 && (reinterpret_cast<uintptr_t>(base) & 63) == 0; }
 
 int resolve_opts(const hg_plan_opts *in, hg::Opts &o) {
   if (in) {
@@ -433,7 +435,8 @@ int run_hop(const hg_plan *p, int hop, int32_t F, const int32_t *ptr, const int3
   // Streaming (nt) stores for the hop's output: always for hop 2 (rows of Y); for hop 1 when Xe [M, F] is larger than
   // about three quarters of the 256 MiB Infinity Cache -- a smaller table is read straight back from it by hop 2 and plain stores keep it
   // there (same-box A/B, profiles/r03_experiments.md: 348-695 MB tables -3..-6 %, 2-143 MB tables +9..+16 % with nt)
-  const bool nt_out = hop == 1 || (int64_t)p->M * F * 4 >= ((int64_t)192 << 20);
+  // -- and only for rows of whole 64-byte units (F % 16 == 0): others lose with the hint (hg_kernels.hip, HG_Y_NT)
+  const bool nt_out = rows_whole_64(dst, F) && (hop == 1 || (int64_t)p->M * F * 4 >= ((int64_t)192 << 20));
   int kind = 0;  // hg_plan_tune_f32's choice for this hop and width: 0 streaming, 1 panels + tasks, 2 latency schedule
   {
     hg_plan *mp = const_cast<hg_plan *>(p);
@@ -1032,6 +1035,7 @@ static int aggr_impl(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
     a.mat_bytes = mat_bytes;
     a.nrows_x = plan->N;
     a.nrows_mat = f->n_mat;
+    a.y_nt = rows_whole_64(Y, F);
     a.bsA = bound ? f->d_bsA : nullptr;
     a.bsB = bound ? f->d_bsB : nullptr;
     a.bsD = bound ? f->d_bsD : nullptr;
@@ -1051,7 +1055,7 @@ static int aggr_impl(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
     if (e != hipSuccess) return hip_fail("fused_panel launch", e);
     // (d) hubs and split vertices: Y[v] = degV[v] * (sum of the vertex's partial rows), fixed order
     if (!f->fixups.empty()) {
-      e = hg::launch_fixups(f->d_fixups, (int)f->fixups.size(), f->n_fix_l1, F, partial, Y, degV, nullptr, nullptr, vec4, s, true);
+      e = hg::launch_fixups(f->d_fixups, (int)f->fixups.size(), f->n_fix_l1, F, partial, Y, degV, nullptr, nullptr, vec4, s, rows_whole_64(Y, F));
       if (e != hipSuccess) return hip_fail("fixup launch", e);
     }
     return HG_OK;

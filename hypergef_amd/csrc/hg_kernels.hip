@@ -22,8 +22,10 @@ namespace hg {
 #ifndef HG_ROWS_WAVES
 #define HG_ROWS_WAVES 7
 #endif
-// Rows of Y leave the panel kernel with the streaming (nt) hint.  Same-box A/B, round 3 (tools/nt_probe.sh, then
-// tools/ab_lib.sh against a -DHG_Y_NT=0 build): see profiles/r03_experiments.md.
+// Rows of Y leave the panel kernel with the streaming (nt) hint where a row is whole 64-byte units (F % 16 == 0: the
+// host sets FusedArgs::y_nt / GatherArgs::nt_dst / StreamArgs::nt_dst): +3..8 % there, F = 16 0.45 -> 0.72 of the
+// roofline; rows that end inside a 64-byte unit (F = 4 .. 28, 33) lose 7-50 % with it -- the L2 merges their partial
+// lines only on the plain write-back path (tools/nt_widths.sh, profiles/r03_experiments.md).
 #ifndef HG_Y_NT
 #define HG_Y_NT 1
 #endif
@@ -1098,7 +1100,7 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
         const int pr = prow[r];  // vertex id, or bit 31 | partial row (a piece of a split vertex)
         float *dst = (pr < 0 ? a.partial + (int64_t)(pr & 0x7fffffff) * F : a.Y + (int64_t)pr * F) + col;
         if (DBG && (a.debug & 64)) acc.store_nt(dst);
-        else if (HG_Y_NT && pr >= 0) acc.store_n_nt(dst, a.F - col);  // partial rows are read back by the fixup pass: plain
+        else if (HG_Y_NT && a.y_nt && pr >= 0) acc.store_n_nt(dst, a.F - col);  // partial rows are read back by the fixup pass: plain
         else acc.store_n(dst, a.F - col);
       }
     }
