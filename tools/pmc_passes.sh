@@ -1,6 +1,8 @@
 #!/bin/bash
 # Memory-system counter passes for one bench configuration (separate rocprofv3 --pmc runs, as the
-# MI355X guide prescribes).  usage: tools/pmc_passes.sh <outdir-under-gpurun_out> <bench.py flags...>
+# MI355X guide prescribes).  At most four counters per pass, and FETCH_SIZE never beside other TCC counters (it takes
+# three of the four TCC slots: round 2's gpurun_out/pmc_f8/p1 aborted with "Request exceeds the capabilities of the
+# hardware to collect"); FETCH_SIZE / WRITE_SIZE passes live in tools/profile_config.sh.  usage: tools/pmc_passes.sh <outdir-under-gpurun_out> <bench.py flags...>
 out=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 i=0
