@@ -227,6 +227,37 @@ int get_fused(const hg_plan *cp, int32_t F, bool vec4, const hg::FusedSched **ou
             }
           }
         }
+        // A tiny dense hypergraph (zoo: 43 hyperedges of ~28 of the 101 vertices) needs nearly every hyperedge in
+        // every panel, so more panels do not shorten a workgroup's hop-1 stream -- 1221 gathers over the 32 lane
+        // groups of a 256-thread workgroup are 38 dependent steps.  A 1024-thread workgroup has four times the lane
+        // groups: the whole graph in one or a few such panels, nothing materialised, one launch.
+        const int32_t lanes = row_floats / (vec4 ? 4 : 1);
+        if (p->opts.fused_tile_auto && vec4 && F % 4 == 0 && (lanes == 8 || lanes == 16) && p->nnz <= 16384 && p->N <= 4096 &&
+            wide_rows_ok(p, F)) {
+          for (int32_t tile : {16384, 32768, 65536}) {
+            int32_t c2, m2;
+            fused_caps(p, F, vec4, c2, m2, tile);
+            for (int mode = 1; mode < 4; mode++) {
+              hg::Opts o = p->opts;
+              if (mode == 1) {
+                if (p->sched[0].max_len * 4 > m2) continue;
+                o.t_big = std::max(o.t_big, p->sched[0].max_len);
+              } else {
+                o.slot_chunk = std::max(o.t_big, mode == 2 ? 8 : 16);
+                if (p->sched[0].max_len <= o.slot_chunk) continue;
+              }
+              hg::FusedSched alt;
+              hg::build_fused(p->N, p->M, p->ptr_t.data(), p->ind_t.data(), p->ptr_v.data(), p->ind_v.data(), o, c2, m2,
+                              4 * ng, row_floats, false, alt);
+              if (alt.invalid || alt.n_mat > 0 || !alt.fixups.empty()) continue;
+              const double c = small_graph_cost(alt) + 0.3;  // barriers over sixteen waves
+              if (c < best) {
+                best = c;
+                f = std::move(alt);
+              }
+            }
+          }
+        }
       }
     } catch (const std::bad_alloc &) {
       hg::set_error("fused schedule: host allocation failed");

@@ -887,9 +887,10 @@ typedef int hg_i4 __attribute__((ext_vector_type(4)));
 // the ablation switches (a.debug) in the code; production instances have none.
 // LIN: the rows a panel produces go through panel_times_wt (Y = rows * Wlin^T, F_out columns)
 // instead of straight to Y; needs F == LPR * VEC and at most 4 rows per lane group.
-// BS: threads per panel workgroup.  Only 256 is instantiated: 512- / 1024-thread workgroups with two / four times the
-// tile (the panel shape of F = 32 for rows of 64 and 128 floats, same waves and LDS per CU) were 3-9 % slower on every
-// wide-row batch (profiles/r03_experiments.md).
+// BS: threads per panel workgroup.  256 everywhere but for a tiny dense hypergraph, whose whole hop-1 stream sits in one
+// panel whatever the panel count: 1024 threads then (four times the lane groups, a quarter of the dependent steps).
+// For batches, 512- / 1024-thread workgroups with two / four times the tile (the panel shape of F = 32 for rows of 64
+// and 128 floats, same waves and LDS per CU) were 3-9 % slower on every wide-row batch (profiles/r03_experiments.md).
 // LINW (LIN only): the output may be wider than the input, or a panel hold more row tiles than the staged matrix phase
 // takes -- the direct form is compiled in.  LINW = false instances (F_out <= F, the common case) carry the staged form
 // only and fit 8 waves per SIMD without spills; the direct form's registers used to set the budget of every LIN
@@ -1685,6 +1686,18 @@ template <int LPR, int VEC>
 static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
   if (a.npanels == 0) return hipSuccess;
   constexpr int TW = LPR * VEC;
+  if constexpr (VEC == 4 && (LPR == 8 || LPR == 16)) {
+    // a tiny dense hypergraph as one or a few 1024-thread panels (hg_api.hip, get_fused): nothing materialised there
+    if (a.ng == 1024 / LPR) {
+      const bool fast = a.x_bytes > 0 && a.nrows_x < (1 << 24) && a.F < (1 << 22) && (a.F & 3) == 0;
+      if (!fast || a.Wlin || a.Xe_mat) return hipErrorInvalidValue;
+      const dim3 grid(a.npanels, (a.F + TW - 1) / TW);
+      const size_t lds = (size_t)a.cap * TW * 4 + (size_t)a.max_rec_words * 4 +
+                         (size_t)(((a.degE || a.W) ? 2 * a.cap : 0) + (a.degV ? a.rows_cap : 0)) * 4 + 16;
+      if (a.degE || a.W) return launch_lds<fused_packed_kernel<LPR, VEC, 8, true, false, true, false, false, 1024>, 1024>(grid, lds, stream, a);
+      return launch_lds<fused_packed_kernel<LPR, VEC, 8, true, false, false, false, false, 1024>, 1024>(grid, lds, stream, a);
+    }
+  }
   if (a.ng != 256 / LPR) return hipErrorInvalidValue;  // records were packed for another lane layout
   const int col_tiles = (a.F + TW - 1) / TW;
   const Tuning &t = tuning();
