@@ -344,3 +344,36 @@ def test_launch_bound_graphs_get_small_panels_and_sub_slots(hg):
     assert info["n_mat"] == 0 and info["fixups"] == 0 and p.auto_variant(32) == "fused"
     assert info["slots"] > planmod.Plan.from_host(cs.N, cs.M, cs.csrptr, cs.colind,
                                                   planmod.make_opts(host_only=True, fused_tile_bytes=16384)).prepare(32)["slots"] // 2
+
+
+def test_options_resolution_needs_no_gpu(hg):
+    """ops.Options: validation, per-thread nesting of `with ops.options(...)`, process defaults through the set_*
+    functions -- the resolution order every operator call uses (explicit > thread-local > defaults)."""
+    import threading
+    from hypergef_amd import ops
+    base = ops.current_options()
+    assert base == ops.Options() and base.variant == "auto" and base.backward == "reference"
+    with pytest.raises(ValueError):
+        ops.Options(fuse_linear="sometimes")
+    with pytest.raises(ValueError):
+        ops.set_backward("exact")
+    with ops.options(variant="pull") as outer:
+        assert ops.current_options() is outer
+        with ops.options(backward="adjoint") as inner:
+            assert inner.variant == "pull" and inner.backward == "adjoint" and ops.current_options() is inner
+            seen = []
+            t = threading.Thread(target=lambda: seen.append(ops.current_options()))
+            t.start()
+            t.join()
+            assert seen == [base]
+        assert ops.current_options() is outer
+    assert ops.current_options() == base
+    ops.set_fuse_linear("never")
+    try:
+        assert ops.current_options().fuse_linear == "never" and ops._opt(None).fuse_linear == "never"
+        explicit = ops.Options(fuse_linear="always")
+        assert ops._opt(explicit) is explicit
+    finally:
+        ops.set_fuse_linear("auto")
+    with pytest.raises(TypeError):
+        ops._opt("pull")
