@@ -330,7 +330,8 @@ static void one_graph(std::mt19937 &rng, int N, int M, double mean, int hub_ever
         }
         hg::FusedSched f;
         // 8 lanes x 4 floats per row, as F = 32; or (small hub tiles) 32 lanes x 4 floats, as F = 128
-        const int ng = (hubs && cap != 64) ? 8 : 32, row_floats = (hubs && cap != 64) ? 128 : 32;
+        // ... or (sub-slot schedules, 128-slot tiles) the 128 lane groups of a 1024-thread panel for tiny dense graphs
+        const int ng = (hubs == 2 && cap == 128) ? 128 : (hubs && cap != 64) ? 8 : 32, row_floats = (hubs && cap != 64 && ng != 128) ? 128 : 32;
         hg::build_fused(N, M, ptr.data(), ind.data(), ptr_v.data(), ind_v.data(), oh, cap, cap * 4, ng, row_floats, true, f);
         if (hubs == 2) {
           if (f.invalid) continue;  // a vertex's sub-slots exceed a panel: the plan discards such a schedule
