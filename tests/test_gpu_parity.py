@@ -1325,6 +1325,36 @@ def test_tables_beyond_2GiB_use_64bit_offsets(hg, oracle, K, F):
     torch.cuda.empty_cache()
 
 
+def test_vertex_ids_beyond_24_bits(hg, oracle):
+    """More than 2^24 vertices: the fast path's 24-bit row arithmetic (v_mad_u32_u24 byte offsets, buffer
+    descriptors) does not apply and the kernels must take their 64-bit-offset forms -- fused (recomputed and
+    materialised slots), pull, push -- with members and outputs on both sides of row 2^24."""
+    from hypergef_amd.plan import Plan
+    N, M, F = (1 << 24) + 4096, 60000, 8  # more than 2^18 incidences: the throughput schedule, which materialises
+    rng = np.random.default_rng(24)
+    sizes = rng.integers(2, 14, M)
+    pool = np.concatenate([rng.integers(0, 50000, 60000), rng.integers((1 << 24) - 40000, N, 60000)])
+    rows = [np.unique(rng.choice(pool, s, replace=False)) for s in sizes]
+    csrptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    inc = synth.Incidence(N, M, csrptr, np.concatenate(rows).astype(np.int32), name="wide-ids")
+    assert inc.colind.max() >= 1 << 24
+    X = np.zeros((N, F), np.float32)
+    touched = np.unique(inc.colind)
+    X[touched] = rng.standard_normal((touched.size, F)).astype(np.float32)
+    H_ptr, H_ind = vertex_csr(inc, oracle)
+    ref = oracle.hyperaggr_host(N, F, H_ptr, H_ind, inc.csrptr, inc.colind, X)
+    ptr, ind, Xd = _dev(inc.csrptr), _dev(inc.colind), _dev(X)
+    plan = Plan.from_tensors(N, ptr, ind)
+    assert plan.prepare(F)["n_mat"] > 0
+    for variant in ("fused", "pull", "push_atomic", "auto"):
+        y = plan.aggregate(ptr, ind, Xd, variant=variant).cpu().numpy()
+        assert not y[np.setdiff1d(np.arange(0, N, 4097), touched)].any()  # untouched rows are written, as zeros
+        _assert_close(y[touched], ref[touched])
+        assert np.abs(y - ref).max() <= 1e-5 * max(1.0, float(np.abs(ref).max()))
+    del Xd
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("seed", list(range(int(os.environ.get("HG_FUZZ_SEEDS", "12")))))  # a soak run sets HG_FUZZ_SEEDS higher
 def test_random_graphs_widths_and_options_differential(hg, oracle, seed):
     """Differential sweep: per seed a random hypergraph family (uniform, heavy-tailed with hub vertices, a
