@@ -1325,6 +1325,30 @@ def test_tables_beyond_2GiB_use_64bit_offsets(hg, oracle, K, F):
     torch.cuda.empty_cache()
 
 
+def test_more_than_2_24_hyperedges(hg, oracle):
+    """M beyond 2^24 (tiny hyperedges over few vertices, so every vertex sits in ~125 of them): the hub pass's round
+    records hold 24-bit rows of the materialised table and must not be chosen (the plan once checked N only and the
+    launch then failed); the big vertices become pieces, and the pull variant's Xe is a 1 GB table."""
+    from hypergef_amd.plan import Plan
+    M, N, F = (1 << 24) + 1000, 200_000, 16
+    rng = np.random.default_rng(5)
+    sizes = rng.integers(1, 3, M)
+    csrptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    inc = synth.Incidence(N, M, csrptr, rng.integers(0, N, int(csrptr[-1])).astype(np.int32), name="many-hyperedges")
+    X = synth.features_like_reference(N, F, seed=6)
+    H_ptr, H_ind = vertex_csr(inc, oracle)
+    ref = oracle.hyperaggr_host(N, F, H_ptr, H_ind, inc.csrptr, inc.colind, X)
+    ptr, ind, Xd = _dev(inc.csrptr), _dev(inc.colind), _dev(X)
+    plan = Plan.from_tensors(N, ptr, ind)
+    info = plan.prepare(F)
+    assert info["n_hub"] == 0 and info["n_split"] > 1000
+    for variant in ("pull", "fused"):
+        y = plan.aggregate(ptr, ind, Xd, variant=variant).cpu().numpy()
+        np.testing.assert_allclose(y, ref, rtol=1e-5, atol=0)  # ~190 non-negative terms per row
+    del Xd
+    torch.cuda.empty_cache()
+
+
 def test_vertex_ids_beyond_24_bits(hg, oracle):
     """More than 2^24 vertices: the fast path's 24-bit row arithmetic (v_mad_u32_u24 byte offsets, buffer
     descriptors) does not apply and the kernels must take their 64-bit-offset forms -- fused (recomputed and
