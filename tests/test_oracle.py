@@ -151,3 +151,30 @@ def test_check_result_is_relative_only(oracle):
     assert oracle.check_result(np.array([[1.005, 0.0]], np.float32), ref)
     assert not oracle.check_result(np.array([[1.02, 0.0]], np.float32), ref)
     assert not oracle.check_result(np.array([[1.0, 1e-9]], np.float32), ref)  # ref == 0 demands exact 0
+
+
+@pytest.mark.parametrize("shape", ["cora", "pubmed", "ragged"])
+def test_against_the_scatter_formulation_in_torch(oracle, shape):
+    """A third independent statement of the operator: the reference's PyG layer (model/pygnn/hgnn.py:25-38) --
+    gather X[vertex], scatter-sum by hyperedge, scale by degE then W, gather Xe[edges], scatter-sum by vertex,
+    scale by degV -- written with torch index_add_ on the CPU (torch_scatter's sum is the same accumulation).  Same
+    fp32 arithmetic in the same order as the oracle's HGNN_check restatement: it must agree to the last bit or two."""
+    import torch
+    inc = {"cora": synth.cora_shape, "pubmed": synth.pubmed_shape,
+           "ragged": lambda: synth.random_incidence(500, 300, 6.0, seed=3, empty_frac=0.1)}[shape]()
+    F = 6
+    rng = np.random.default_rng(12)
+    X = rng.standard_normal((inc.N, F)).astype(np.float32)
+    W = (rng.random(inc.M) + 0.5).astype(np.float32)
+    H_ptr, H_ind = vertex_csr(inc, oracle)
+    degE, degV = oracle.degrees(inc.N, inc.M, inc.csrptr, inc.colind)
+    degE = np.where(np.isinf(degE), 0, degE).astype(np.float32)
+    vertex = torch.from_numpy(inc.colind.astype(np.int64))
+    edges = torch.from_numpy(np.repeat(np.arange(inc.M, dtype=np.int64), np.diff(inc.csrptr)))
+    Xt = torch.from_numpy(X)
+    Xe = torch.zeros(inc.M, F).index_add_(0, edges, Xt[vertex])
+    Xe = Xe * torch.from_numpy(degE.reshape(-1, 1))
+    Xe = Xe * torch.from_numpy(W.reshape(-1, 1))
+    Xv = torch.zeros(inc.N, F).index_add_(0, vertex, Xe[edges]) * torch.from_numpy(degV.reshape(-1, 1))
+    Y = oracle.hgnn_check(inc.N, inc.M, F, H_ptr, H_ind, inc.csrptr, inc.colind, X, degE, degV, W)
+    np.testing.assert_allclose(Y, Xv.numpy(), rtol=3e-7, atol=1e-7)
