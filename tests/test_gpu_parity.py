@@ -1364,7 +1364,9 @@ def test_vertex_ids_beyond_24_bits(hg, oracle):
     assert inc.colind.max() >= 1 << 24
     X = np.zeros((N, F), np.float32)
     touched = np.unique(inc.colind)
-    X[touched] = rng.standard_normal((touched.size, F)).astype(np.float32)
+    # non-negative features (the reference's fill_random_h values): no cancellation, so the atomics' arbitrary order
+    # (push) stays inside the relative bound too
+    X[touched] = (rng.integers(0, 10, (touched.size, F)) / 10.0).astype(np.float32)
     H_ptr, H_ind = vertex_csr(inc, oracle)
     ref = oracle.hyperaggr_host(N, F, H_ptr, H_ind, inc.csrptr, inc.colind, X)
     ptr, ind, Xd = _dev(inc.csrptr), _dev(inc.colind), _dev(X)
