@@ -19,12 +19,10 @@ Backward: the reference returns `forward(grad_out)` for every sum operator
 only when degV is absent; `set_backward("adjoint")` selects
 H diag(degE W) H^T diag(degV) grad instead.  Default: "reference".
 """
-import ctypes
-
 import torch
 
 from . import _lib
-from .plan import (Plan, cached_plan, linear_fusion_pays, linear_rows, linear_supported, linear_wgrad,
+from .plan import (cached_plan, linear_fusion_pays, linear_rows, linear_supported, linear_wgrad,
                    wgrad_supported, _check_feat, _check_index, _ptr, _stream_handle)
 
 import contextlib
