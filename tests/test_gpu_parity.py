@@ -1406,6 +1406,13 @@ def test_random_graphs_widths_and_options_differential(hg, oracle, seed):
                                      seed=seed, empty_frac=0.5)
     else:
         inc = synth.powerlaw(60_000, 200_000, seed=seed)  # a vertex in tens of thousands of hyperedges
+    if seed % 4 == 3:  # duplicate incidences (a vertex listed twice in a hyperedge counts twice): 3 % of the entries doubled
+        reps = np.where(rng.random(inc.nnz) < 0.03, 2, 1)
+        eid = np.repeat(np.arange(inc.M), np.diff(inc.csrptr))
+        cnt = np.zeros(inc.M + 1, np.int64)
+        np.add.at(cnt, eid + 1, reps)
+        inc = synth.Incidence(inc.N, inc.M, np.cumsum(cnt).astype(np.int32), np.repeat(inc.colind, reps).astype(np.int32),
+                              name=inc.name + "+dups")
     H_ptr, H_ind = vertex_csr(inc, oracle)
     degE, degV = oracle.degrees(inc.N, inc.M, inc.csrptr, inc.colind)
     degE = np.where(np.isinf(degE), 0, degE).astype(np.float32)
