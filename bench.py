@@ -233,6 +233,24 @@ def float64_report(Y_dev, inc, X_host, scales, weight=None, scale_by_max=False):
             "float64_bound": "1e-5*max(1,max|ref|)" if scale_by_max else "1e-5*max(1,|ref|)"}
 
 
+def floor_of(roofline, copy_gbs):
+    """What the bytes this schedule moves (PMC traffic, profiles/traffic.json) cost at the rate the guide calls
+    achievable (6.3 TB/s) and at the rate a plain device copy reached in this very run: the step time below which
+    this decomposition cannot go, next to the time it takes."""
+    t = roofline.get("traffic")
+    if not t:
+        return
+    balg = roofline["algorithmic_bytes_per_step"]
+    roofline["floor"] = {
+        "traffic_over_algorithmic": t / balg,
+        "ms_at_6300_GBs": t / 6.3e12 * 1e3, "frac_at_6300_GBs": balg / (t / 6.3e12) / 1e9 / HBM_PEAK_GBS,
+        "device_copy_GBs_this_run": copy_gbs,
+        "ms_at_device_copy_rate": t / (copy_gbs * 1e9) * 1e3,
+        "frac_at_device_copy_rate": balg / (t / (copy_gbs * 1e9)) / 1e9 / HBM_PEAK_GBS,
+        "note": "PMC bytes of this schedule / a bandwidth: the time (and fraction of the 8 TB/s roofline on algorithmic "
+                "bytes) this decomposition cannot beat; measured avg_step_us is beside it"}
+
+
 def parity_report(Y_dev, ref, nrows, inc):
     """Timed output vs the oracle.  Bound per row: 1e-5 * max(1, |ref|) (BASELINE.json north_star)
     plus the oracle's own worst-case rounding, u * (longest sequential chain feeding the row) --
@@ -596,6 +614,8 @@ def main():
                                       "aggregation step time / this"}
         if args.shape != "powerlaw":
             out["single_graph"] = single_graph_latency(st, F, dev, sync, args.shape)
+        copy_gbs = out["device_copy"]["gbs"]
+        floor_of(out["roofline"], copy_gbs)
     del st
     torch.cuda.empty_cache()
 
@@ -622,6 +642,8 @@ def main():
                 for k in ("plan", "plan_build_s"):
                     r.pop(k, None)
                 failed = failed or ("parity" in r and not r["parity"]["ok"])
+                if "device_copy" in out:
+                    floor_of(r["roofline"], out["device_copy"]["gbs"])
                 configs.append(r)
             except Exception as exc:
                 configs.append({"workload": workload_name(shape, reps, feat), "error": str(exc)[:300]})
