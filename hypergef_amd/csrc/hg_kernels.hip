@@ -705,10 +705,12 @@ __device__ __forceinline__ void panel_times_wt(float *t, int nrows, int F_out, c
 #pragma unroll
         for (int i = 0; i < KSTEPS; i++) bv[i] = bpre[i];
       }
-      for (int rt = sp.rt_first; rt < RT; rt += 4 * sp.rt_step) {
-        const int n = min(4, (RT - rt + sp.rt_step - 1) / sp.rt_step);  // wave-uniform
+      // two row tiles per pass (four would make this path's 16 + 12 + KSTEPS live registers the kernel's budget)
+      for (int rt = sp.rt_first; rt < RT; rt += 2 * sp.rt_step) {
+        const int n = min(2, (RT - rt + sp.rt_step - 1) / sp.rt_step);  // wave-uniform
         hg_f4 acc[4];
-        mfma_rows_n<KSTEPS>(n, t, LD, rt, sp.rt_step, bv, acc, lane);
+        if (n == 2) mfma_rows<KSTEPS, 2>(t, LD, rt, sp.rt_step, bv, acc, lane);
+        else mfma_rows<KSTEPS, 1>(t, LD, rt, sp.rt_step, bv, acc, lane);
         store_tiles(nt, rt, n, acc);
       }
     }
@@ -721,7 +723,7 @@ template <int KSTEPS> struct LinearRows {
   static constexpr int R = KSTEPS >= 32 ? 32 : 64;
 };
 template <int KSTEPS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KSTEPS >= 32 ? 5 : HG_ROWS_WAVES, 8))) void linear_rows_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KSTEPS >= 32 ? 6 : KSTEPS >= 16 ? HG_ROWS_WAVES : 8, 8))) void linear_rows_kernel(
     const LinearArgs a) {
   constexpr int K = KSTEPS * 4, LD = K + 4, R = LinearRows<KSTEPS>::R;
   __shared__ float t[R * LD];
@@ -863,7 +865,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *partial,
 // (tools/linear_probe.py, cora x1024): F = 32 -> 32: 8 waves 0.262 ms, 7 0.258, 6 0.236, 5 0.249; 64 -> 64: 8 waves
 // 0.621, 7 0.539, 6 0.507, 5 0.529, 4 0.532; 128 -> 128 (x256): 6 waves 0.739 (spills), 5 0.370, 4 0.388.
 #ifndef HG_LIN_WAVES8
-#define HG_LIN_WAVES8 6
+#define HG_LIN_WAVES8 8
 #endif
 #ifndef HG_LIN_WAVES16
 #define HG_LIN_WAVES16 6

@@ -25,7 +25,7 @@ def timed(fn, n=50, warm=5):
 rows = []
 CONFIGS = (("cora", 1024, 32, 32), ("cora", 1024, 64, 64), ("cora", 256, 128, 128),
                               ("cora", 1024, 64, 16), ("citeseer", 1024, 64, 64), ("pubmed", 64, 128, 128),
-                              ("pubmed", 64, 128, 64))
+                              ("pubmed", 64, 128, 64), ("cora", 1024, 32, 64), ("cora", 1024, 32, 48), ("cora", 1024, 64, 128))
 for shape, K, F_in, F_out in CONFIGS[int(os.environ.get("PROBE_FROM", "0")):int(os.environ.get("PROBE_ONLY", "99"))]:
     inc = synth.replicate_block_diagonal(getattr(synth, shape + "_shape")(), K)
     ptr, ind = torch.from_numpy(inc.csrptr).to(dev), torch.from_numpy(inc.colind).to(dev)
