@@ -384,8 +384,16 @@ def hgnnaggr_linear(csrptr_t, indices_t, node_feat, weight, degE=None, degV=None
 def hgnnaggr(balan_key, balan_row, group_st, group_ed, csrptr_t, indices_t, node_feat, degE, degV, W, options=None):
     """hgnnaggr with fused degE and degV.  (`options`: this backend's per-call Options; the reference's ten
     positional arguments are unchanged.)"""
-    return _SumAggr.apply(balan_key, balan_row, group_st, group_ed, csrptr_t, indices_t, node_feat,
-                          degE, degV, W, _opt(options))
+    return _sum_aggr(balan_key, balan_row, group_st, group_ed, csrptr_t, indices_t, node_feat, degE, degV, W, options)
+
+
+def _sum_aggr(balan_key, balan_row, group_st, group_ed, csrptr_t, indices_t, node_feat, degE, degV, W, options):
+    opt = _opt(options)
+    # nothing to differentiate (inference, or a feature tensor outside the graph): the operator itself, without the
+    # autograd node -- a third of the host cost of a launch-bound call
+    if not (torch.is_grad_enabled() and isinstance(node_feat, torch.Tensor) and node_feat.requires_grad):
+        return _forward((balan_key, balan_row, group_st, group_ed), csrptr_t, indices_t, node_feat, degE, degV, W, opt)
+    return _SumAggr.apply(balan_key, balan_row, group_st, group_ed, csrptr_t, indices_t, node_feat, degE, degV, W, opt)
 
 
 def _edge_sizes(csrptr_t):
@@ -468,13 +476,11 @@ def hgnnaggr_max(csrptr_t, indices_t, node_feat, degE, degV, W):
 # ---- module `unignnaggr` (unignnaggr.cc:81-102) ------------------------------
 
 def unignnaggrdeg(balan_key, balan_row, group_st, group_ed, csrptr_t, indices_t, node_feat, degE, degV, options=None):
-    return _SumAggr.apply(balan_key, balan_row, group_st, group_ed, csrptr_t, indices_t, node_feat,
-                          degE, degV, None, _opt(options))
+    return _sum_aggr(balan_key, balan_row, group_st, group_ed, csrptr_t, indices_t, node_feat, degE, degV, None, options)
 
 
 def unignnaggr(balan_key, balan_row, group_st, group_ed, csrptr_t, indices_t, node_feat, options=None):
-    return _SumAggr.apply(balan_key, balan_row, group_st, group_ed, csrptr_t, indices_t, node_feat,
-                          None, None, None, _opt(options))
+    return _sum_aggr(balan_key, balan_row, group_st, group_ed, csrptr_t, indices_t, node_feat, None, None, None, options)
 
 
 # the names the reference's Python wrapper actually calls (unignnconv.py:7,10);

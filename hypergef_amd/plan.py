@@ -115,6 +115,7 @@ class Plan:
         """Build the feature-width dependent (fused) schedule now; returns its shape."""
         info = _lib.FusedInfo()
         _lib.check(_lib.lib().hg_plan_prepare(self._h, F, ctypes.byref(info)))
+        self.__dict__.setdefault("_ws_bytes", {}).pop(F, None)
         return info.as_dict()
 
     def auto_variant(self, F):
@@ -143,6 +144,7 @@ class Plan:
                 _ptr(workspace), nbytes, int(iters), _stream_handle(X.device), ctypes.byref(info)))
         if hasattr(self, "_auto"):
             self._auto.pop(F, None)  # the cached answer of auto_variant may have changed
+        self.__dict__.setdefault("_ws_bytes", {}).pop(F, None)
         names = {code: name for name, code in _lib.VARIANTS.items()}
         kinds = ("stream", "panels", "tasks")  # per hop: streaming row gather, row panels + wave tasks, latency schedule
         labels = ("fused", "pull") + tuple("pull/%s+%s" % (kinds[c % 3], kinds[c // 3]) for c in range(1, 9))
@@ -157,7 +159,13 @@ class Plan:
             self._prepared.add(F)
 
     def workspace_bytes(self, F):
-        return int(_lib.lib().hg_plan_workspace_bytes(self._h, F))
+        # cached per width: asking costs a library call per aggregation otherwise; prepare / tune, which can build a
+        # larger layout for the width, drop the entry
+        cache = self.__dict__.setdefault("_ws_bytes", {})
+        n = cache.get(F)
+        if n is None:
+            n = cache[F] = int(_lib.lib().hg_plan_workspace_bytes(self._h, F))
+        return n
 
     def _workspace(self, F, device):
         nbytes = self.workspace_bytes(F)
@@ -179,8 +187,9 @@ class Plan:
                 if t.numel() != n:
                     raise ValueError("%s must have %d elements, got %d" % (name, n, t.numel()))
         W = self._drop_unit_weights(W, bind_scales)
+        stream = torch.cuda.current_stream(X.device)  # looked up once per call: it is a measurable share of a launch-bound call
         if (degE is not None or degV is not None or W is not None) and variant in ("auto", "fused"):
-            self._bind_scales(F, degE, degV, W, X.device, bind_scales)
+            self._bind_scales(F, degE, degV, W, X.device, bind_scales, stream)
         Y = out if out is not None else torch.empty((self.N, F), dtype=torch.float32, device=X.device)
         if variant == "fused":  # hg_plan_workspace_bytes sizes for what AUTO runs; a forced fused call needs its schedule first
             self._ensure_fused(F)
@@ -191,7 +200,7 @@ class Plan:
         with torch.cuda.device(X.device):
             _lib.check(_lib.lib().hg_aggr_fused_f32(
                 self._h, F, _ptr(csrptr_t), _ptr(colind_t), _ptr(X), _ptr(degE), _ptr(degV), _ptr(W),
-                _ptr(Y), _ptr(workspace), nbytes, _lib.VARIANTS[variant], _stream_handle(X.device)))
+                _ptr(Y), _ptr(workspace), nbytes, _lib.VARIANTS[variant], ctypes.c_void_p(stream.cuda_stream)))
         return Y
 
     def aggregate_linear(self, csrptr_t, colind_t, X, weight, degE=None, degV=None, W=None,
@@ -262,7 +271,7 @@ class Plan:
             self._unit_w_misses = 0 if hit[0] else self._unit_w_misses + 1
         return None if hit[0] else W
 
-    def _bind_scales(self, F, degE, degV, W, device, enable=True):
+    def _bind_scales(self, F, degE, degV, W, device, enable=True, stream=None):
         """Degree / weight vectors are graph constants: pre-gather them into the fused
         schedule's panel order once (hg_plan_bind_scales) and again only when a tensor is
         replaced or modified in place (data_ptr / torch version counter).
@@ -285,7 +294,8 @@ class Plan:
             self.unbind(F)
             return
         key = tuple(None if t is None else (t.data_ptr(), t._version) for t in (degE, degV, W))
-        stream = torch.cuda.current_stream(device)
+        if stream is None:
+            stream = torch.cuda.current_stream(device)
         hit = self._bound.get(F)
         if hit is not None and hit[0] == key:
             if hit[2] != stream.cuda_stream:
