@@ -1067,6 +1067,8 @@ static int aggr_impl(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
     a.nrows_x = plan->N;
     a.nrows_mat = f->n_mat;
     a.y_nt = rows_whole_64(Y, F);
+    // a pre-pass that read at least a quarter of the incidences' member rows: see fused_packed_kernel's run order
+    a.reverse_runs = f->n_mat > 0 && !f->mat_ptr.empty() && (int64_t)f->mat_ptr.back() * 4 >= plan->nnz;
     a.bsA = bound ? f->d_bsA : nullptr;
     a.bsB = bound ? f->d_bsB : nullptr;
     a.bsD = bound ? f->d_bsD : nullptr;

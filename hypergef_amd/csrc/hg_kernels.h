@@ -59,6 +59,7 @@ struct FusedArgs {
   int32_t nrows_mat = 0;  // rows of the materialised table
   int32_t debug = 0;      // ablation / stamp bits (experiments only)
   int32_t y_nt = 0;       // rows of Y leave with the streaming (nt) hint: set for rows of whole 64-byte units (F % 16 == 0)
+  int32_t reverse_runs = 0;  // each XCD walks its run of panels backwards (set after a substantial materialisation pre-pass)
   // fused linear epilogue (hg_aggr_linear_f32): Y[N, F_out] = (aggregated rows) * Wlin^T
   const float *Wlin = nullptr;  // Wlin [F_out, F] in MFMA fragment order (launch_linear_pack), or null
   int32_t F_out = 0;
