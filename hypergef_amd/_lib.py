@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HG_AGGR_LIB") or os.path.join(_HERE, "lib", "libhgaggr.so")
 
 HG_OK = 0
+HG_ERR_WORKSPACE = -4  # include/hg_aggr.h: caller workspace smaller than hg_plan_workspace_bytes
 HG_VARIANT_AUTO = 0
 HG_VARIANT_PULL = 1
 HG_VARIANT_PUSH_ATOMIC = 2

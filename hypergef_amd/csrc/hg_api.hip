@@ -173,10 +173,34 @@ double small_graph_cost(const hg::FusedSched &f) {
 }
 
 // The F-dependent part of the plan, built on first use (guarded by the plan's mutex).
-int get_fused(const hg_plan *cp, int32_t F, bool vec4, const hg::FusedSched **out) {
-  hg_plan *p = const_cast<hg_plan *>(cp);
-  int32_t cap, mem_cap;
+// The linear epilogue (hg_aggr_linear_f32) multiplies a panel's finished rows in 16-row MFMA tiles, at most four rows
+// per lane group: a panel of 24 rows pays for 32.  Its schedule therefore caps the ROWS of a panel at 4 per lane group
+// (F = 128: 32, F = 64: 64 -- whole tiles) and gives the panel half as many slots again, so that the rows run out before
+// the slots do (pubmed-shape, F = 128: 32 slots hold 24 rows on average; 48 hold the 32).  lin_caps() returns false
+// where the default schedule is already that shape (F = 32: 128 rows of 128 slots) or the caller fixed the tile.
+bool lin_caps(const hg_plan *p, int32_t F, bool vec4, int32_t &cap, int32_t &mem_cap, int32_t &rows_cap) {
+  if (!vec4 || (F != 64 && F != 128) || !p->opts.fused_tile_auto || p->opts.fused_steps > 0 || p->nnz <= (1 << 18)) return false;
+  int pct = 150;
+#ifdef HG_TUNING
+  if (const char *e = getenv("HG_LIN_SLOTS_PCT")) pct = atoi(e);  // diagnostic build: 0 = the default schedule
+#endif
+  if (pct <= 0) return false;
   fused_caps(p, F, vec4, cap, mem_cap);
+  const int32_t ng = 256 / (hg::fused_tile_row_floats(F, vec4) / 4);
+  rows_cap = std::min(cap, 4 * ng);
+#ifdef HG_TUNING
+  if (const char *e = getenv("HG_LIN_ROWS_CAP")) rows_cap = std::max(16, std::min(rows_cap, atoi(e) / 16 * 16));
+#endif
+  cap = std::max(cap, (rows_cap * pct / 100 + 15) / 16 * 16);
+  mem_cap = cap * 4;
+  return true;
+}
+
+int get_fused(const hg_plan *cp, int32_t F, bool vec4, const hg::FusedSched **out, bool lin = false) {
+  hg_plan *p = const_cast<hg_plan *>(cp);
+  int32_t cap, mem_cap, rows_cap = 0;
+  if (lin && !lin_caps(p, F, vec4, cap, mem_cap, rows_cap)) lin = false;
+  if (!lin) fused_caps(p, F, vec4, cap, mem_cap);
   const int32_t row_floats = hg::fused_tile_row_floats(F, vec4);
   const int32_t ng = 256 / (row_floats / (vec4 ? 4 : 1));  // lane groups per workgroup
   // The hub pass reads X and the materialised table through buffer descriptors (row index below 2^24,
@@ -184,14 +208,14 @@ int get_fused(const hg_plan *cp, int32_t F, bool vec4, const hg::FusedSched **ou
   // (rows of the materialised table are masked to 24 bits in the round records too, and n_mat <= M)
   const bool allow_hub = vec4 && F % 4 == 0 && F >= 16 && p->N < (1 << 24) && p->M < (1 << 24) && (int64_t)p->N * F * 4 < ((int64_t)1 << 31) &&
                          (int64_t)p->M * F * 4 < ((int64_t)1 << 31);
-  const int64_t key = (((int64_t)cap * 1000000 + mem_cap) * 1000 + ng) * 2 + (allow_hub ? 1 : 0);
+  const int64_t key = ((((int64_t)cap * 1000000 + mem_cap) * 1000 + ng) * 2 + (allow_hub ? 1 : 0)) * 1024 + rows_cap;
   std::lock_guard<std::mutex> lock(p->fused_mu);
   auto it = p->fused.find(key);
   if (it == p->fused.end()) {
     hg::FusedSched f;
     try {
       hg::build_fused(p->N, p->M, p->ptr_t.data(), p->ind_t.data(), p->ptr_v.data(), p->ind_v.data(),
-                      p->opts, cap, mem_cap, ng, row_floats, allow_hub, f);
+                      p->opts, cap, mem_cap, ng, row_floats, allow_hub, f, rows_cap);
       // A small hypergraph is launch-bound (small_graph_cost).  Two things can shorten it: recomputing the
       // few longish hyperedges too instead of a materialisation launch (one citeseer-shape hypergraph
       // 15.8 -> 8.2 us at F = 32), and -- unless the caller fixed the tile -- smaller panels: more, shorter
@@ -287,7 +311,7 @@ int get_fused(const hg_plan *cp, int32_t F, bool vec4, const hg::FusedSched **ou
     }
     it = p->fused.emplace(key, std::move(f)).first;
   }
-  p->fused_by_width[(int64_t)F * 2 + (vec4 ? 1 : 0)] = &it->second;
+  p->fused_by_width[((int64_t)F * 2 + (vec4 ? 1 : 0)) * 2 + (lin ? 1 : 0)] = &it->second;
   *out = &it->second;
   return HG_OK;
 }
@@ -326,7 +350,7 @@ size_t workspace_need(const hg_plan *cp, int32_t F, bool pull_only = false) {
   if (pull_only) return need;
   std::lock_guard<std::mutex> lock(p->fused_mu);
   for (const auto &kv : p->fused_by_width)
-    if (kv.first / 2 == F) need = std::max(need, fused_carve(*kv.second, F).total);
+    if (kv.first / 4 == F) need = std::max(need, fused_carve(*kv.second, F).total);
   return need;
 }
 
@@ -729,6 +753,20 @@ int hg_plan_get_schedule(const hg_plan *p, int32_t hop, int32_t *panels, int32_t
   return HG_OK;
 }
 
+// degE[e] / W[e] per slot and degV[v] per panel row of schedule f, in record order (buffers allocated on first use)
+static int gather_bound_scales(hg::FusedSched *f, const float *degE, const float *degV, const float *W, hipStream_t stream) {
+  const size_t ns = f->eid_all.size(), nr = f->prow.size();
+  if (!f->d_bsA && ns > 0) {
+    HG_HIP(hipMalloc(reinterpret_cast<void **>(&f->d_bsA), ns * sizeof(float)));
+    HG_HIP(hipMalloc(reinterpret_cast<void **>(&f->d_bsB), ns * sizeof(float)));
+  }
+  if (!f->d_bsD && nr > 0) HG_HIP(hipMalloc(reinterpret_cast<void **>(&f->d_bsD), nr * sizeof(float)));
+  hipError_t e = hg::launch_bind_scales((int64_t)ns, f->d_eid_all, degE, W, f->d_bsA, f->d_bsB, (int64_t)nr,
+                                        f->d_prow, degV, f->d_bsD, stream);
+  if (e != hipSuccess) return hip_fail("bind_scales launch", e);
+  return HG_OK;
+}
+
 int hg_plan_bind_scales(const hg_plan *cp, int32_t F, const float *degE, const float *degV,
                         const float *W, hg_stream_t stream) {
   if (!cp || F <= 0 || (cp->opts.flags & HG_PLAN_HOST_ONLY)) {
@@ -740,20 +778,19 @@ int hg_plan_bind_scales(const hg_plan *cp, int32_t F, const float *degE, const f
   if (rc != HG_OK) return rc;
   hg::FusedSched *f = const_cast<hg::FusedSched *>(cf);
   std::lock_guard<std::mutex> lock(const_cast<hg_plan *>(cp)->fused_mu);
+  // the linear epilogue's own schedule of this width (if one was built) follows: it is re-bound on its next use
+  for (const auto &kv : cp->fused_by_width)
+    if (kv.first / 4 == F && (kv.first & 1) && kv.second != cf) {
+      hg::FusedSched *fl = const_cast<hg::FusedSched *>(kv.second);
+      fl->bound_degE = fl->bound_W = fl->bound_degV = nullptr;
+      fl->bound_W_is_one = false;
+    }
   if (!degE && !degV && !W) {  // unbind: later calls gather their scales themselves
     f->bound_degE = f->bound_W = f->bound_degV = nullptr;
     f->bound_W_is_one = false;
     return HG_OK;
   }
-  const size_t ns = f->eid_all.size(), nr = f->prow.size();
-  if (!f->d_bsA && ns > 0) {
-    HG_HIP(hipMalloc(reinterpret_cast<void **>(&f->d_bsA), ns * sizeof(float)));
-    HG_HIP(hipMalloc(reinterpret_cast<void **>(&f->d_bsB), ns * sizeof(float)));
-  }
-  if (!f->d_bsD && nr > 0) HG_HIP(hipMalloc(reinterpret_cast<void **>(&f->d_bsD), nr * sizeof(float)));
-  hipError_t e = hg::launch_bind_scales((int64_t)ns, f->d_eid_all, degE, W, f->d_bsA, f->d_bsB, (int64_t)nr,
-                                        f->d_prow, degV, f->d_bsD, static_cast<hipStream_t>(stream));
-  if (e != hipSuccess) return hip_fail("bind_scales launch", e);
+  if ((rc = gather_bound_scales(f, degE, degV, W, static_cast<hipStream_t>(stream))) != HG_OK) return rc;
   // W = ones is what the reference's models pass (model/ugsys/hgnn.py:12): x * 1.0f is x, so a bound all-ones W
   // is left out of the kernels.  One 4-byte read-back: this call synchronises `stream` when W is given.
   bool w_one = false;
@@ -836,6 +873,24 @@ int hg_plan_prepare(const hg_plan *p, int32_t F, hg_fused_info *info) {
 // fused kernel when HG_FUSED_DEBUG has bit 32 set.
 __attribute__((visibility("default"))) int hg_debug_read_stamps(unsigned long long *out8, int reset) {
   return hg::read_stamps(out8, reset != 0) == hipSuccess ? HG_OK : HG_ERR_HIP;
+}
+
+// Diagnostic only (not declared in hg_aggr.h): shape of the fused schedule of width F -- lin != 0: the linear epilogue's
+// own one -- out = {panels, rows, rows padded to 16-row tiles, member entries, slots, cap, rows_cap, n_mat, fixups}.
+__attribute__((visibility("default"))) int hg_debug_fused_shape(const hg_plan *p, int32_t F, int32_t lin, int64_t *out9) {
+  const hg::FusedSched *f = nullptr;
+  int rc = get_fused(p, F, plan_vec4(p, F), &f, lin != 0);
+  if (rc != HG_OK) return rc;
+  int64_t rows = 0, padded = 0, slots = 0;
+  for (const auto &pn : f->panels) {
+    rows += pn.nrows;
+    padded += (pn.nrows + 15) / 16 * 16;
+    slots += pn.nslots;
+  }
+  const int64_t v[9] = {(int64_t)f->panels.size(), rows, padded, f->pmem_entries, slots, f->cap, f->rows_cap, f->n_mat,
+                        (int64_t)f->fixups.size()};
+  for (int i = 0; i < 9; i++) out9[i] = v[i];
+  return HG_OK;
 }
 
 size_t hg_plan_workspace_bytes(const hg_plan *p, int32_t F) {
@@ -973,6 +1028,26 @@ static int aggr_impl(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
   }
   if (variant == HG_VARIANT_FUSED) {
     if (!f && (rc = get_fused(plan, F, vec4, &f)) != HG_OK) return rc;
+    if (lin && aligned && f->fixups.empty()) {
+      // the epilogue's own schedule (whole 16-row tiles per panel, get_fused); its scales follow the default
+      // schedule's binding -- gathered here on first use, on this call's stream, which every later use is ordered behind
+      // or waits for through the caller's binding event (plan.py, _bind_scales)
+      const hg::FusedSched *fl = nullptr;
+      if ((rc = get_fused(plan, F, vec4, &fl, true)) != HG_OK) return rc;
+      if (fl != f && fl->fixups.empty()) {
+        const bool dflt_bound = (degE || degV || W) && f->bound_degE == degE && f->bound_W == W && f->bound_degV == degV;
+        if (dflt_bound && !(fl->bound_degE == degE && fl->bound_W == W && fl->bound_degV == degV)) {
+          hg::FusedSched *m = const_cast<hg::FusedSched *>(fl);
+          std::lock_guard<std::mutex> lock(const_cast<hg_plan *>(plan)->fused_mu);
+          if ((rc = gather_bound_scales(m, degE, degV, W, s)) != HG_OK) return rc;
+          m->bound_degE = degE;
+          m->bound_W = W;
+          m->bound_degV = degV;
+          m->bound_W_is_one = f->bound_W_is_one;
+        }
+        f = fl;
+      }
+    }
     const FusedCarve fc = fused_carve(*f, F);
     if (fc.total > 0 && (!workspace || fc.total > workspace_bytes)) {
       hg::set_error("workspace too small for the fused schedule: need " + std::to_string(fc.total) + " bytes, got " +
@@ -1258,9 +1333,19 @@ int hg_linear_wgrad_f32(int64_t nrows, int32_t F_a, int32_t F_b, const float *A,
   return HG_OK;
 }
 
+// the base layout once the epilogue's own schedule exists too (it is what a fused call with a linear runs)
+static size_t linear_base_bytes(const hg_plan *plan, int32_t F_in) {
+  int32_t variant = HG_VARIANT_PULL;
+  const hg::FusedSched *f = nullptr;
+  const bool vec4 = plan_vec4(plan, F_in);
+  if (pick_variant(plan, F_in, vec4, &variant, &f) == HG_OK && variant == HG_VARIANT_FUSED && f && f->fixups.empty())
+    (void)get_fused(plan, F_in, vec4, &f, true);
+  return workspace_need(plan, F_in);
+}
+
 size_t hg_aggr_linear_workspace_bytes(const hg_plan *plan, int32_t F_in) {
   if (!plan || F_in <= 0) return 0;
-  return hg_plan_workspace_bytes(plan, F_in) + round256((size_t)plan->N * F_in * sizeof(float));
+  return linear_base_bytes(plan, F_in) + round256((size_t)plan->N * F_in * sizeof(float));
 }
 
 int hg_aggr_linear_res_f32(const hg_plan *plan, int32_t F_in, int32_t F_out, const int32_t *csrptr_t,
@@ -1280,8 +1365,8 @@ int hg_aggr_linear_res_f32(const hg_plan *plan, int32_t F_in, int32_t F_out, con
     hg::set_error("hg_aggr_linear_f32: push-atomic variant not supported");
     return HG_ERR_UNSUPPORTED;
   }
-  const size_t base = hg_plan_workspace_bytes(plan, F_in);
-  if (!workspace || workspace_bytes < hg_aggr_linear_workspace_bytes(plan, F_in)) {
+  const size_t base = linear_base_bytes(plan, F_in);  // asked once: the query runs the AUTO rule under the plan's locks
+  if (!workspace || workspace_bytes < base + round256((size_t)plan->N * F_in * sizeof(float))) {
     hg::set_error("hg_aggr_linear_f32: workspace smaller than hg_aggr_linear_workspace_bytes");
     return HG_ERR_WORKSPACE;
   }

@@ -129,10 +129,11 @@ static void pack_stream(const std::vector<SlotRange> &slots, const int32_t *mem,
 
 void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_t,
                  const int32_t *ptr_v, const int32_t *ind_v, const Opts &o, int32_t cap,
-                 int32_t mem_cap, int32_t ng, int32_t row_floats, bool allow_hub, FusedSched &f) {
+                 int32_t mem_cap, int32_t ng, int32_t row_floats, bool allow_hub, FusedSched &f,
+                 int32_t rows_cap) {
   f = FusedSched();
   f.cap = cap;
-  f.rows_cap = cap;
+  f.rows_cap = rows_cap > 0 ? std::min(rows_cap, cap) : cap;
   f.mem_cap = mem_cap;
   f.vslot_cap = cap * 2;
   f.t_big = std::max(1, std::min(o.t_big, f.mem_cap));

@@ -224,9 +224,12 @@ void classify_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *p
                     const Opts &o, int32_t cap, int32_t mem_cap, int64_t *n_mat, int64_t *n_big);
 // row_floats: floats per LDS tile row (the kernels' TW); allow_hub: the hub pass may be used
 // (buffer-addressable tables).
+// rows_cap: rows per panel (0 = as many as slots).  The linear epilogue's schedule asks for fewer rows than slots:
+// whole 16-row MFMA tiles, reached before the slots run out.
 void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_t,
                  const int32_t *ptr_v, const int32_t *ind_v, const Opts &o, int32_t cap,
-                 int32_t mem_cap, int32_t ng, int32_t row_floats, bool allow_hub, FusedSched &f);
+                 int32_t mem_cap, int32_t ng, int32_t row_floats, bool allow_hub, FusedSched &f,
+                 int32_t rows_cap = 0);
 // rows [0, nrows) of the CSR (ptr, ind) as a RowStream; scale_index[r] (or r itself if null) names the
 // row's scale factors; idle = rows of the gathered table
 void build_row_stream(int32_t nrows, const int32_t *ptr, const int32_t *ind, const int32_t *scale_index,
@@ -250,7 +253,7 @@ struct hg_plan {
   hg::Sched sched_lat[2];
   bool has_lat = false;
   std::map<int64_t, hg::FusedSched> fused;  // keyed by (slot, entry) capacity: depends on F
-  std::map<int64_t, const hg::FusedSched *> fused_by_width;  // (F, vec4) -> the schedule built for it
+  std::map<int64_t, const hg::FusedSched *> fused_by_width;  // (F, vec4, lin) -> the schedule built for it
   std::mutex fused_mu;
   // pull variant on the streaming row gather: schedules per (hop, lane groups), built on first use
   std::map<int64_t, hg::RowStream> row_streams;

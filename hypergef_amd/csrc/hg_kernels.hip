@@ -1730,7 +1730,7 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
   return staged ? launch_lds<fused_packed_kernel<LPR, VEC, 8, true, M, S, false, true, 256, false>>(grid, lds_l, stream, ad) \
                 : launch_lds<fused_packed_kernel<LPR, VEC, 8, true, M, S, false, true, 256, true>>(grid, lds_l, stream, ad)
 #ifdef HG_TUNING
-        if (t.fused_debug & 768)  // ablations of the matrix phase (tools/linear_probe.py): diagnostic build only
+        if (t.fused_debug & (768 | 1))  // ablations of the matrix phase / the gathers (tools/linear_probe.py): diagnostic build only
           return launch_lds<fused_packed_kernel<LPR, VEC, 8, true, true, true, true, true>>(grid, lds_l, stream, ad);
 #endif
         switch (spec) {
@@ -1833,9 +1833,9 @@ bool fused_linear_ok(const FusedArgs &a) {
   const Tuning &t = tuning();
   const int lpr = a.F / 4;
   return (a.F == 32 || a.F == 64 || a.F == 128) && a.F_out > 0 && (a.F_out & 15) == 0 && t.fused_fast &&
-         !(t.fused_debug & 255) && a.x_bytes > 0 && a.nrows_x < (1 << 24) &&
+         !(t.fused_debug & 254) && a.x_bytes > 0 && a.nrows_x < (1 << 24) &&
          (!a.Xe_mat || (a.mat_bytes > 0 && a.nrows_mat < (1 << 24))) &&
-         a.ng == 256 / lpr && a.rows_cap <= 4 * (256 / lpr) && a.rows_cap == a.cap;
+         a.ng == 256 / lpr && a.rows_cap <= 4 * (256 / lpr) && a.rows_cap <= a.cap;
 }
 
 hipError_t launch_linear(const LinearArgs &a, hipStream_t stream) {

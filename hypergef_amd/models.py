@@ -33,7 +33,7 @@ class HyperGsysHGNN(nn.Module):
     def __init__(self, hyperg, in_channels, out_channels, first_aggr, heads=1, options=None):
         super().__init__()
         self.options = options
-        self.W = ops.Linear(in_channels, heads * out_channels, bias=False)
+        self.W = ops.Linear(in_channels, heads * out_channels, bias=False, options=options)
         self.Wdiag = torch.ones(hyperg.degE.shape[0]).to(hyperg.device)
         self.heads, self.in_channels, self.out_channels = heads, in_channels, out_channels
         self.hyperg, self.degE, self.degV = hyperg, hyperg.degE, hyperg.degV
@@ -51,7 +51,7 @@ class HyperGsysUinGINConv(nn.Module):
     def __init__(self, hyperg, in_channels, out_channels, first_aggr, heads=1, options=None):
         super().__init__()
         self.options = options
-        self.W = ops.Linear(in_channels, heads * out_channels, bias=False)
+        self.W = ops.Linear(in_channels, heads * out_channels, bias=False, options=options)
         self.heads, self.in_channels, self.out_channels = heads, in_channels, out_channels
         self.hyperg, self.degE, self.degV = hyperg, hyperg.degE, hyperg.degV
         self.eps = nn.parameter.Parameter(torch.FloatTensor([0]))
@@ -80,7 +80,7 @@ class HyperGsysUniGCNII(nn.Module):
     def __init__(self, hyperg, in_channels, out_channels, heads=1, options=None):
         super().__init__()
         self.options = options
-        self.W = ops.Linear(in_channels, out_channels, bias=False)
+        self.W = ops.Linear(in_channels, out_channels, bias=False, options=options)
         self.heads, self.in_channels, self.out_channels = heads, in_channels, out_channels
         self.hyperg, self.degE, self.degV = hyperg, hyperg.degE, hyperg.degV
 
@@ -202,7 +202,10 @@ class UniGCNII(nn.Module):
         self.act = {"relu": nn.ReLU(), "prelu": nn.PReLU()}[args.activation]
         self.input_drop = nn.Dropout(args.input_drop)
         self.dropout = nn.Dropout(args.dropout)
-        lin = nn.Linear if getattr(args, "backend", "hgsys") == "torch" else ops.Linear  # same module, own wgrad kernel
+        if getattr(args, "backend", "hgsys") == "torch":
+            lin = nn.Linear
+        else:  # same module, own wgrad kernel, under the model's options like its conv layers
+            lin = lambda i, o: ops.Linear(i, o, options=getattr(args, "options", None))
         self.convs = nn.ModuleList([lin(nfeat, nhid)])
         if getattr(args, "backend", "hgsys") == "torch":
             tg = _TorchGraph(hyperg, getattr(args, "device", hyperg.device))

@@ -210,10 +210,10 @@ class _LinearFn(torch.autograd.Function):
     (x^T-style contraction over the vertices; see _wgrad)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, opt=None):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        ctx.mode = current_options().fuse_linear
+        ctx.mode = _opt(opt).fuse_linear  # the owning module's pinned Options, else the caller's (thread, process)
         return torch.nn.functional.linear(x, weight, bias)
 
     @staticmethod
@@ -223,16 +223,24 @@ class _LinearFn(torch.autograd.Function):
         gx = _rows_times(grad, weight, ctx.mode) if ctx.needs_input_grad[0] else None
         gw = _wgrad(grad, x, ctx.mode) if ctx.needs_input_grad[1] else None
         gb = grad.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        return gx, gw, gb
+        return gx, gw, gb, None
 
 
 class Linear(torch.nn.Linear):
     """Drop-in nn.Linear (same parameters, same state_dict) for the [N, F] activations of these
-    models: identical forward, weight gradient on hg_linear_wgrad_f32."""
+    models: identical forward, weight gradient on hg_linear_wgrad_f32.  `options` (an ops.Options, or None for the
+    caller's) pins what the backward may use, like the conv modules' own: a model built with
+    Options(fuse_linear="never") keeps its linears off the library's MFMA kernels too."""
+
+    def __init__(self, in_features, out_features, bias=True, device=None, dtype=None, options=None):
+        super().__init__(in_features, out_features, bias=bias, device=device, dtype=dtype)
+        if options is not None and not isinstance(options, Options):
+            raise TypeError("options must be an ops.Options")
+        self.options = options
 
     def forward(self, x):
         if x.dim() == 2 and x.is_cuda and x.dtype == torch.float32:
-            return _LinearFn.apply(x, self.weight, self.bias)
+            return _LinearFn.apply(x, self.weight, self.bias, self.options)
         return super().forward(x)
 
 

@@ -115,7 +115,8 @@ class Plan:
         """Build the feature-width dependent (fused) schedule now; returns its shape."""
         info = _lib.FusedInfo()
         _lib.check(_lib.lib().hg_plan_prepare(self._h, F, ctypes.byref(info)))
-        self.__dict__.setdefault("_ws_bytes", {}).pop(F, None)
+        for k in (F, ("lin", F)):
+            self.__dict__.setdefault("_ws_bytes", {}).pop(k, None)
         return info.as_dict()
 
     def auto_variant(self, F):
@@ -144,7 +145,8 @@ class Plan:
                 _ptr(workspace), nbytes, int(iters), _stream_handle(X.device), ctypes.byref(info)))
         if hasattr(self, "_auto"):
             self._auto.pop(F, None)  # the cached answer of auto_variant may have changed
-        self.__dict__.setdefault("_ws_bytes", {}).pop(F, None)
+        for k in (F, ("lin", F)):
+            self.__dict__.setdefault("_ws_bytes", {}).pop(k, None)
         names = {code: name for name, code in _lib.VARIANTS.items()}
         kinds = ("stream", "panels", "tasks")  # per hop: streaming row gather, row panels + wave tasks, latency schedule
         labels = ("fused", "pull") + tuple("pull/%s+%s" % (kinds[c % 3], kinds[c // 3]) for c in range(1, 9))
@@ -165,6 +167,15 @@ class Plan:
         n = cache.get(F)
         if n is None:
             n = cache[F] = int(_lib.lib().hg_plan_workspace_bytes(self._h, F))
+        return n
+
+    def linear_workspace_bytes(self, F_in):
+        """hg_aggr_linear_workspace_bytes, cached per width like workspace_bytes (the query runs the AUTO rule under the
+        plan's locks and may build a schedule: not something to pay per launch-bound layer call)."""
+        cache = self.__dict__.setdefault("_ws_bytes", {})
+        n = cache.get(("lin", F_in))
+        if n is None:
+            n = cache[("lin", F_in)] = int(_lib.lib().hg_aggr_linear_workspace_bytes(self._h, F_in))
         return n
 
     def _workspace(self, F, device):
@@ -193,14 +204,24 @@ class Plan:
         Y = out if out is not None else torch.empty((self.N, F), dtype=torch.float32, device=X.device)
         if variant == "fused":  # hg_plan_workspace_bytes sizes for what AUTO runs; a forced fused call needs its schedule first
             self._ensure_fused(F)
-        if workspace is None:
+        own_ws = workspace is None
+        if own_ws:
             workspace, nbytes = self._workspace(F, X.device)
         else:
             nbytes = workspace.numel() * workspace.element_size()
         with torch.cuda.device(X.device):
-            _lib.check(_lib.lib().hg_aggr_fused_f32(
-                self._h, F, _ptr(csrptr_t), _ptr(colind_t), _ptr(X), _ptr(degE), _ptr(degV), _ptr(W),
-                _ptr(Y), _ptr(workspace), nbytes, _lib.VARIANTS[variant], ctypes.c_void_p(stream.cuda_stream)))
+            args = (self._h, F, _ptr(csrptr_t), _ptr(colind_t), _ptr(X), _ptr(degE), _ptr(degV), _ptr(W), _ptr(Y))
+            st = _lib.lib().hg_aggr_fused_f32(*args, _ptr(workspace), nbytes, _lib.VARIANTS[variant],
+                                              ctypes.c_void_p(stream.cuda_stream))
+            if st == _lib.HG_ERR_WORKSPACE and own_ws:
+                # The cached size is stale: the call itself built a layout for this width that needs more (e.g. AUTO on an
+                # unaligned view of X with N >= 2^24 takes another schedule than the one the size was asked for).  Nothing
+                # was written; ask again and retry once.
+                self.__dict__.setdefault("_ws_bytes", {}).pop(F, None)
+                workspace, nbytes = self._workspace(F, X.device)
+                st = _lib.lib().hg_aggr_fused_f32(*args, _ptr(workspace), nbytes, _lib.VARIANTS[variant],
+                                                  ctypes.c_void_p(stream.cuda_stream))
+            _lib.check(st)
         return Y
 
     def aggregate_linear(self, csrptr_t, colind_t, X, weight, degE=None, degV=None, W=None,
@@ -235,9 +256,9 @@ class Plan:
         Y = out if out is not None else torch.empty((self.N, F_out), dtype=torch.float32, device=X.device)
         if variant == "fused":
             self._ensure_fused(F_in)
-        if workspace is None:
-            nbytes = int(_lib.lib().hg_aggr_linear_workspace_bytes(self._h, F_in))
-            workspace = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=X.device)
+        own_ws = workspace is None
+        if own_ws:
+            workspace = torch.empty(max(self.linear_workspace_bytes(F_in), 256), dtype=torch.uint8, device=X.device)
         nbytes = workspace.numel() * workspace.element_size()
         with torch.cuda.device(X.device):
             for name, t in (("residual", residual), ("t_out", t_out)):
@@ -245,10 +266,16 @@ class Plan:
                     _check_feat(t, name, device=X.device)
                     if tuple(t.shape) != (self.N, F_in):
                         raise ValueError("%s must be [N, F_in]" % name)
-            _lib.check(_lib.lib().hg_aggr_linear_res_f32(
-                self._h, F_in, F_out, _ptr(csrptr_t), _ptr(colind_t), _ptr(X), _ptr(degE), _ptr(degV),
-                _ptr(W), _ptr(weight), _ptr(residual), float(ca), float(cb), 1 if relu else 0, _ptr(t_out),
-                _ptr(Y), _ptr(workspace), nbytes, _lib.VARIANTS[variant], _stream_handle(X.device)))
+            head = (self._h, F_in, F_out, _ptr(csrptr_t), _ptr(colind_t), _ptr(X), _ptr(degE), _ptr(degV),
+                    _ptr(W), _ptr(weight), _ptr(residual), float(ca), float(cb), 1 if relu else 0, _ptr(t_out), _ptr(Y))
+            stream = _stream_handle(X.device)
+            st = _lib.lib().hg_aggr_linear_res_f32(*head, _ptr(workspace), nbytes, _lib.VARIANTS[variant], stream)
+            if st == _lib.HG_ERR_WORKSPACE and own_ws:  # stale cached size: see aggregate()
+                self.__dict__.setdefault("_ws_bytes", {}).pop(("lin", F_in), None)
+                workspace = torch.empty(max(self.linear_workspace_bytes(F_in), 256), dtype=torch.uint8, device=X.device)
+                nbytes = workspace.numel()
+                st = _lib.lib().hg_aggr_linear_res_f32(*head, _ptr(workspace), nbytes, _lib.VARIANTS[variant], stream)
+            _lib.check(st)
         return Y
 
     def _drop_unit_weights(self, W, enable=True):

@@ -19,15 +19,47 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+# ---- one tolerance helper per determinism class -----------------------------------------------------------------
+# (a) same summation order as the oracle (rows no longer than short_max, slots in CSR order): np.array_equal.
+# (b) deterministic kernels (pull / fused / auto) whose order may differ from the oracle's (wave tasks, pieces, hubs):
+#     _assert_close -- north_star's |y - ref| <= 1e-5 * max(1, |ref|) plus the reference test's own verdict,
+#     torch.allclose(rtol=1e-4, atol=1e-6) (test/hgnn_test.py:92).
+# (c) kernels whose order is free (push_atomic / push_groups: fp32 atomics land in arbitrary order, as the
+#     reference's own atomicAdd kernels do, hgnnaggr_cuda.cu:28-45): _assert_close_any_order -- against the float64
+#     answer at 1e-5 * max(1, l1 mass of the element), the bound that holds for ANY order of a sum's terms (an
+#     element that cancelled to ~0 out of terms of size ~1 cannot be right to 1e-6, whatever kernel adds it).
+# Inputs are never chosen to dodge a bound: randn features stay randn for every class.
+
 def _tol_ok(y, ref):
     return np.abs(y - ref) <= 1e-5 * np.maximum(1.0, np.abs(ref))
 
 
-def _assert_close(y, ref):
+def _where(bad, y, ref, what):
+    """Which variant / case failed and where: the first offending elements with both values."""
+    idx = np.argwhere(bad)[:4]
+    cells = ", ".join("%s: got %.9g want %.9g" % (tuple(int(v) for v in i), y[tuple(i)], ref[tuple(i)]) for i in idx)
+    return "%s: %d of %d elements off, max |err| %g; %s" % (what or "?", int(bad.sum()), bad.size, float(np.abs(y - ref).max()), cells)
+
+
+def _assert_close(y, ref, what=""):
     y = y.detach().cpu().numpy() if hasattr(y, "detach") else y
     bad = ~_tol_ok(y, ref)
-    assert not bad.any(), "max err %g at %s" % (np.abs(y - ref).max(), np.argwhere(bad)[:4])
-    assert np.allclose(y, ref, rtol=1e-4, atol=1e-6)
+    assert not bad.any(), _where(bad, y, ref, what)
+    bad = ~np.isclose(y, ref, rtol=1e-4, atol=1e-6)
+    assert not bad.any(), "allclose(1e-4, 1e-6) " + _where(bad, y, ref, what)
+
+
+def _assert_close_any_order(y, inc, X, degE=None, degV=None, W=None, what=""):
+    """Class (c): against the float64 answer, 1e-5 of the element's l1 mass (Dv H De W H^T |X|)."""
+    y = y.detach().cpu().numpy() if hasattr(y, "detach") else y
+    truth = _float64_truth(inc, X, degE, degV, W)
+    mass = _float64_truth(inc, np.abs(X), None if degE is None else np.abs(degE), None if degV is None else np.abs(degV),
+                          None if W is None else np.abs(W))
+    bad = np.abs(y - truth) > 1e-5 * np.maximum(1.0, mass)
+    assert not bad.any(), "vs float64 at 1e-5 of the l1 mass, " + _where(bad, y, truth, what)
+
+
+ANY_ORDER = ("push_atomic", "push_groups")
 
 
 def _make(name):
@@ -70,15 +102,15 @@ def test_unweighted_matches_reference_host_path(hg, oracle, shape, F):
     ptr, ind = _dev(inc.csrptr), _dev(inc.colind)
     plan = Plan.from_tensors(inc.N, ptr, ind)
     Y = plan.aggregate(ptr, ind, _dev(X), variant="pull").cpu().numpy()
-    _assert_close(Y, ref)
+    _assert_close(Y, ref, "pull")
     if plan.info["max_len"][0] <= plan.info["short_max"] and plan.info["max_len"][1] <= plan.info["short_max"]:
         assert np.array_equal(Y, ref), "short rows must reproduce the CPU order bit for bit"
     Yf = plan.aggregate(ptr, ind, _dev(X), variant="fused").cpu().numpy()
-    _assert_close(Yf, ref)
+    _assert_close(Yf, ref, "fused")
     if plan.info["max_len"][0] <= 8 and plan.info["max_len"][1] <= 16:
         assert np.array_equal(Yf, ref), "fused panels keep the CPU order too"
     Yp = plan.aggregate(ptr, ind, _dev(X), variant="push_atomic").cpu().numpy()
-    _assert_close(Yp, ref)
+    _assert_close_any_order(Yp, inc, X, what="push_atomic")
 
 
 @pytest.mark.parametrize("shape", ["cora", "citeseer", "pubmed", "ragged", "dense", "powerlaw"])
@@ -98,10 +130,10 @@ def test_hgnnaggr_matches_hgnn_check(hg, oracle, shape, F):
         finally:
             hg.ops.set_variant("auto")
         assert Y.shape == (inc.N, F) and Y.device.type == "cuda"
-        if variant in ("pull", "fused") or shape not in ("dense", "powerlaw"):
-            _assert_close(Y, ref)
-        else:  # atomics on hub rows: thousands of terms in arbitrary order
-            np.testing.assert_allclose(Y.cpu().numpy(), ref, rtol=2e-4, atol=2e-5)
+        if variant in ANY_ORDER:  # atomics: the terms land in arbitrary order
+            _assert_close_any_order(Y, inc, X, degE, degV, W, what="%s %s F=%d" % (variant, shape, F))
+        else:
+            _assert_close(Y, ref, "%s %s F=%d" % (variant, shape, F))
 
 
 def test_short_rows_bit_exact_with_weights(hg, oracle):
@@ -214,7 +246,8 @@ def test_reference_schedule_drives_push_kernel(hg, oracle):
             Y = hg.HGNNAggr(hyperg, _dev(X), _dev(degE), _dev(degV), _dev(W))
         finally:
             hg.ops.set_variant("auto")
-        _assert_close(Y, ref)
+        _assert_close_any_order(Y, inc, X, degE, degV, W, what="push_groups ngs=%d" % ngs)
+        assert np.abs(Y.cpu().numpy() - ref).max() <= 1e-5 * max(1.0, float(np.abs(ref).max()))
 
 
 def test_autograd_backward_modes(hg, oracle):
@@ -994,7 +1027,7 @@ def test_options_are_per_call_and_follow_the_forward_into_backward(hg, oracle):
     from hypergef_amd import models, ops
     inc = _make("cora")
     F = 16
-    X, degE, degV, W, H_ptr, H_ind = _inputs(inc, F, oracle, seed=18)  # non-negative: the push variants' atomic order is free
+    X, degE, degV, W, H_ptr, H_ind = _inputs(inc, F, oracle, seed=18, normal=True)
     hyperg = hg.HyperGraph.from_incidence(inc, DEV, data_name="cora")
     g = torch.from_numpy(np.random.default_rng(19).standard_normal((inc.N, F)).astype(np.float32)).to(DEV)
     ref = oracle.hgnn_check(inc.N, inc.M, F, H_ptr, H_ind, inc.csrptr, inc.colind, X, degE, degV, W)
@@ -1005,7 +1038,11 @@ def test_options_are_per_call_and_follow_the_forward_into_backward(hg, oracle):
     # explicit options on the reference's own wrapper; the defaults stay untouched
     for variant in ("pull", "fused", "push_atomic", "push_groups"):
         y = hg.HGNNAggr(hyperg, _dev(X), hyperg.degE, hyperg.degV, _dev(W), options=ops.Options(variant=variant))
-        _assert_close(y, ref)
+        if variant in ANY_ORDER:
+            _assert_close_any_order(y, inc, X, degE, degV, W, what=variant)
+        else:
+            _assert_close(y, ref, variant)
+            assert np.array_equal(y.cpu().numpy(), ref), variant  # cora: every row short, the CPU order bit for bit
     assert ops.current_options() == ops.Options()
     # forward inside a block, backward outside it: the node remembers "adjoint"
     x1 = _dev(X).requires_grad_(True)
@@ -1364,18 +1401,36 @@ def test_vertex_ids_beyond_24_bits(hg, oracle):
     assert inc.colind.max() >= 1 << 24
     X = np.zeros((N, F), np.float32)
     touched = np.unique(inc.colind)
-    # non-negative features (the reference's fill_random_h values): no cancellation, so the atomics' arbitrary order
-    # (push) stays inside the relative bound too
-    X[touched] = (rng.integers(0, 10, (touched.size, F)) / 10.0).astype(np.float32)
+    X[touched] = rng.standard_normal((touched.size, F)).astype(np.float32)
     H_ptr, H_ind = vertex_csr(inc, oracle)
     ref = oracle.hyperaggr_host(N, F, H_ptr, H_ind, inc.csrptr, inc.colind, X)
     ptr, ind, Xd = _dev(inc.csrptr), _dev(inc.colind), _dev(X)
     plan = Plan.from_tensors(N, ptr, ind)
     assert plan.prepare(F)["n_mat"] > 0
+    # float64 answer and l1 mass on the touched rows only (N = 2^24 + 4096 rows: the full float64 matrices are 2 x 1 GB)
+    import scipy.sparse as sp
+    HT = sp.csr_matrix((np.ones(inc.nnz), inc.colind, inc.csrptr), shape=(M, N))
+    Hrows = HT.T.tocsr()[touched]
+    truth = Hrows @ (HT @ X.astype(np.float64))
+    mass = Hrows @ (HT @ np.abs(X).astype(np.float64))
+    short_rows = np.flatnonzero(np.bincount(inc.colind, minlength=N) <= 16)
     for variant in ("fused", "pull", "push_atomic", "auto"):
         y = plan.aggregate(ptr, ind, Xd, variant=variant).cpu().numpy()
         assert not y[np.setdiff1d(np.arange(0, N, 4097), touched)].any()  # untouched rows are written, as zeros
-        _assert_close(y[touched], ref[touched])
+        if variant in ANY_ORDER:
+            # Round 3's one red run of this test (gpurun_out/gputest7.log) was allclose(1e-4, 1e-6) on an element of small
+            # |ref|, with these same seeded randn inputs, and the test passed on four later runs of the same build.  The
+            # deterministic variants give the same bits on every run, so they cannot pass and fail on one input: the run
+            # that failed was this variant's, whose atomics land in a different order each time -- an element that cancels
+            # to ~1e-3 out of terms of size ~1 (a vertex in up to 46 hyperedges of up to 13 members) is right to
+            # u * (l1 mass) ~ 1e-6..1e-5, not to 1e-6.  The bound for a free order is the l1-mass one.
+            bad = np.abs(y[touched] - truth) > 1e-5 * np.maximum(1.0, mass)
+            assert not bad.any(), "vs float64 at 1e-5 of the l1 mass, " + _where(bad, y[touched], truth, variant)
+        else:
+            _assert_close(y[touched], ref[touched], variant)
+            # rows that every kernel walks sequentially (hyperedges of at most 13 members; vertices in at most 16
+            # hyperedges) keep the CPU order bit for bit
+            assert np.array_equal(y[short_rows], ref[short_rows]), variant
         assert np.abs(y - ref).max() <= 1e-5 * max(1.0, float(np.abs(ref).max()))
     del Xd
     torch.cuda.empty_cache()
