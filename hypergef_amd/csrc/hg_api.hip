@@ -871,8 +871,8 @@ int hg_plan_prepare(const hg_plan *p, int32_t F, hg_fused_info *info) {
 
 // Diagnostic only (not declared in hg_aggr.h): per-phase cycle counters of the
 // fused kernel when HG_FUSED_DEBUG has bit 32 set.
-__attribute__((visibility("default"))) int hg_debug_read_stamps(unsigned long long *out8, int reset) {
-  return hg::read_stamps(out8, reset != 0) == hipSuccess ? HG_OK : HG_ERR_HIP;
+__attribute__((visibility("default"))) int hg_debug_read_stamps(unsigned long long *out16, int reset) {
+  return hg::read_stamps(out16, reset != 0) == hipSuccess ? HG_OK : HG_ERR_HIP;
 }
 
 // Diagnostic only (not declared in hg_aggr.h): shape of the fused schedule of width F -- lin != 0: the linear epilogue's
@@ -1348,10 +1348,10 @@ size_t hg_aggr_linear_workspace_bytes(const hg_plan *plan, int32_t F_in) {
   return linear_base_bytes(plan, F_in) + round256((size_t)plan->N * F_in * sizeof(float));
 }
 
-int hg_aggr_linear_res_f32(const hg_plan *plan, int32_t F_in, int32_t F_out, const int32_t *csrptr_t,
+static int aggr_linear_res(const hg_plan *plan, int32_t F_in, int32_t F_out, const int32_t *csrptr_t,
                            const int32_t *colind_t, const float *X, const float *degE, const float *degV,
-                           const float *W, const float *wfrag, const float *R, float ca, float cb, int32_t relu,
-                           float *T_out, float *Y, void *workspace, size_t workspace_bytes, int32_t variant,
+                           const float *W, const float *wfrag, const float *R, float ca, float cb, const float *cb_dev,
+                           int32_t relu, float *T_out, float *Y, void *workspace, size_t workspace_bytes, int32_t variant,
                            hg_stream_t stream) {
   if (!plan || !wfrag || !Y) {
     hg::set_error("hg_aggr_linear_f32: null argument");
@@ -1379,6 +1379,7 @@ int hg_aggr_linear_res_f32(const hg_plan *plan, int32_t F_in, int32_t F_out, con
   lin.epi.R = R;
   lin.epi.ca = ca;
   lin.epi.cb = R ? cb : 0.f;
+  lin.epi.cb_dev = R ? cb_dev : nullptr;
   lin.epi.relu = relu ? 1 : 0;
   lin.epi.T_out = T_out;
   int rc = aggr_impl(plan, F_in, csrptr_t, colind_t, X, degE, degV, W, T, workspace, base, variant, stream, &lin);
@@ -1395,6 +1396,28 @@ int hg_aggr_linear_res_f32(const hg_plan *plan, int32_t F_in, int32_t F_out, con
   hipError_t e = hg::launch_linear(la, static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return hip_fail("linear_rows launch", e);
   return HG_OK;
+}
+
+int hg_aggr_linear_res_f32(const hg_plan *plan, int32_t F_in, int32_t F_out, const int32_t *csrptr_t,
+                           const int32_t *colind_t, const float *X, const float *degE, const float *degV,
+                           const float *W, const float *wfrag, const float *R, float ca, float cb, int32_t relu,
+                           float *T_out, float *Y, void *workspace, size_t workspace_bytes, int32_t variant,
+                           hg_stream_t stream) {
+  return aggr_linear_res(plan, F_in, F_out, csrptr_t, colind_t, X, degE, degV, W, wfrag, R, ca, cb, nullptr, relu, T_out, Y,
+                         workspace, workspace_bytes, variant, stream);
+}
+
+int hg_aggr_linear_res_dev_f32(const hg_plan *plan, int32_t F_in, int32_t F_out, const int32_t *csrptr_t,
+                               const int32_t *colind_t, const float *X, const float *degE, const float *degV,
+                               const float *W, const float *wfrag, const float *R, float ca, const float *cb_dev,
+                               int32_t relu, float *T_out, float *Y, void *workspace, size_t workspace_bytes,
+                               int32_t variant, hg_stream_t stream) {
+  if (!cb_dev) {
+    hg::set_error("hg_aggr_linear_res_dev_f32: cb_dev is null (use hg_aggr_linear_res_f32 for a host scalar)");
+    return HG_ERR_INVALID;
+  }
+  return aggr_linear_res(plan, F_in, F_out, csrptr_t, colind_t, X, degE, degV, W, wfrag, R, ca, 0.f, cb_dev, relu, T_out, Y,
+                         workspace, workspace_bytes, variant, stream);
 }
 
 int hg_aggr_linear_f32(const hg_plan *plan, int32_t F_in, int32_t F_out, const int32_t *csrptr_t,

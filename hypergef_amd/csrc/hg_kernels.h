@@ -35,6 +35,7 @@ struct GatherArgs {
 struct LinEpilogue {
   const float *R = nullptr;
   float ca = 1.f, cb = 0.f;
+  const float *cb_dev = nullptr;  // non-null: cb is this device scalar, read when the kernel runs (a learned 1 + eps)
   int32_t relu = 0;
   float *T_out = nullptr;
 };

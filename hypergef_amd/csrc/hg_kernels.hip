@@ -313,33 +313,45 @@ __global__ __launch_bounds__(256) void fixup_rows_kernel(const GatherArgs a, con
 // Diagnostic stamps: lane 0 of every wave adds the ticks since the previous stamp to a
 // global counter per phase.  Compiled only into the diagnostic library (`make stamps`,
 // -DHG_STAMPS, then HG_FUSED_DEBUG bit 32); the production kernels carry no stamp code.
-__device__ unsigned long long hg_stamps[8];
+__device__ unsigned long long hg_stamps[16];
 #ifdef HG_STAMPS
-// ticks are summed per wave (scalar registers) and added to the global counters once, at HG_STAMP_FLUSH: one
-// atomic per phase and wave -- an atomic at every stamp serialises thousands of waves on six addresses and
+// ticks are summed per wave (scalar registers) and added to the global counters once, at flush(): one
+// atomic per phase and wave -- an atomic at every stamp serialises thousands of waves on a few addresses and
 // ends up measuring itself
-#define HG_STAMP_INIT(cond)                                  \
-  const bool stamp = ((a.debug & 32) != 0) && (cond);        \
-  unsigned long long st_[6] = {0, 0, 0, 0, 0, 0};            \
-  unsigned long long t0 = stamp ? __builtin_amdgcn_s_memtime() : 0
-#define HG_STAMP(i)                                                        \
-  do {                                                                     \
-    if (stamp) {                                                           \
-      const unsigned long long t1 = __builtin_amdgcn_s_memtime();          \
-      st_[i] += t1 - t0;                                                   \
-      t0 = t1;                                                             \
-    }                                                                      \
-  } while (0)
-#define HG_STAMP_FLUSH()                                                   \
-  do {                                                                     \
-    if (stamp && (threadIdx.x & 63) == 0)                                  \
-      for (int i_ = 0; i_ < 6; i_++) atomicAdd(&hg_stamps[i_], st_[i_]);   \
-  } while (0)
+struct Stamper {
+  bool on = false;
+  unsigned long long st[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t0 = 0;
+  __device__ __forceinline__ void init(bool cond) {
+    on = cond;
+    t0 = on ? __builtin_amdgcn_s_memtime() : 0;
+  }
+  __device__ __forceinline__ void mark(int i) {
+    if (on) {
+      const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+      st[i] += t1 - t0;
+      t0 = t1;
+    }
+  }
+  __device__ __forceinline__ void flush() {
+    if (on && (threadIdx.x & 63) == 0)
+      for (int i = 0; i < 16; i++)
+        if (st[i]) atomicAdd(&hg_stamps[i], st[i]);
+  }
+};
+#define HG_STAMP_INIT(cond) \
+  Stamper stp;              \
+  stp.init(((a.debug & 32) != 0) && (cond))
 #else
-#define HG_STAMP_INIT(cond) do { } while (0)
-#define HG_STAMP(i) do { } while (0)
-#define HG_STAMP_FLUSH() do { } while (0)
+struct Stamper {
+  __device__ __forceinline__ void init(bool) {}
+  __device__ __forceinline__ void mark(int) {}
+  __device__ __forceinline__ void flush() {}
+};
+#define HG_STAMP_INIT(cond) [[maybe_unused]] Stamper stp
 #endif
+#define HG_STAMP(i) stp.mark(i)
+#define HG_STAMP_FLUSH() stp.flush()
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the
 // vector-memory counter, which on CDNA4 counts stores: in a persistent loop that would
@@ -588,7 +600,7 @@ __device__ __forceinline__ void mfma_rows_chunked(const float *ta, int tstep, co
 template <int KSTEPS, int NPW>
 __device__ __forceinline__ void panel_times_wt_staged_chunked(float *t, int nrows, int F_out, const float *Wlin,
                                                               const int32_t *rowmap, int64_t row0, float *Y, int tid,
-                                                              float (&bpre)[8], int relu) {
+                                                              float (&bpre)[8], int relu, Stamper &stp) {
   constexpr int K = KSTEPS * 4, LD = K + 4, RPN = 4 / NPW;
   const int lane = tid & 63;
   const int NT = F_out >> 4, RT = (nrows + 15) >> 4;
@@ -609,7 +621,9 @@ __device__ __forceinline__ void panel_times_wt_staged_chunked(float *t, int nrow
       default: break;
     }
   }
+  HG_STAMP(8);
   __syncthreads();  // every wave has read its A fragments: the rows can be overwritten
+  HG_STAMP(9);
   if (sp.active) {
 #pragma unroll
     for (int ni = 0; ni < NPW; ni++) {
@@ -626,6 +640,7 @@ __device__ __forceinline__ void panel_times_wt_staged_chunked(float *t, int nrow
     }
   }
   __syncthreads();
+  HG_STAMP(10);
   const int q = F_out >> 2;  // float4 pieces per row
   for (int i = tid; i < nrows * q; i += 256) {
     const int r = i / q, c = (i - r * q) * 4;
@@ -635,6 +650,7 @@ __device__ __forceinline__ void panel_times_wt_staged_chunked(float *t, int nrow
     if (HG_Y_NT) Vec<4>{o}.store_nt(Y + yrow * F_out + c);
     else *reinterpret_cast<float4 *>(Y + yrow * F_out + c) = o;
   }
+  HG_STAMP(11);
 }
 
 // WIDE = false: the caller guarantees the staged form applies (F_out <= K and few enough row tiles); the direct form
@@ -642,14 +658,14 @@ __device__ __forceinline__ void panel_times_wt_staged_chunked(float *t, int nrow
 template <int KSTEPS, bool WIDE = true>
 __device__ __forceinline__ void panel_times_wt(float *t, int nrows, int F_out, const float *Wlin,
                                                const int32_t *rowmap, int64_t row0, float *Y, int tid,
-                                               float (&bpre)[BPre<KSTEPS>::N], int relu) {
+                                               float (&bpre)[BPre<KSTEPS>::N], int relu, Stamper &stp) {
   constexpr int K = KSTEPS * 4, LD = K + 4;
   const int nt_all = F_out >> 4, nwr = nt_all >= 3 ? 1 : 4 / nt_all;  // as lin_split
   const int rt_per_wave = (((nrows + 15) >> 4) + nwr - 1) / nwr;
   if (!WIDE || (F_out <= K && rt_per_wave <= (F_out > 64 ? 2 : 4))) {  // workgroup-uniform
     if constexpr (KSTEPS >= 32) {
-      if (F_out > 64) panel_times_wt_staged_chunked<KSTEPS, 2>(t, nrows, F_out, Wlin, rowmap, row0, Y, tid, bpre, relu);
-      else panel_times_wt_staged_chunked<KSTEPS, 1>(t, nrows, F_out, Wlin, rowmap, row0, Y, tid, bpre, relu);
+      if (F_out > 64) panel_times_wt_staged_chunked<KSTEPS, 2>(t, nrows, F_out, Wlin, rowmap, row0, Y, tid, bpre, relu, stp);
+      else panel_times_wt_staged_chunked<KSTEPS, 1>(t, nrows, F_out, Wlin, rowmap, row0, Y, tid, bpre, relu, stp);
     } else {
       if (F_out > 64) panel_times_wt_staged<KSTEPS, 2>(t, nrows, F_out, Wlin, rowmap, row0, Y, tid, bpre, relu);
       else panel_times_wt_staged<KSTEPS, 1>(t, nrows, F_out, Wlin, rowmap, row0, Y, tid, bpre, relu);
@@ -740,6 +756,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KSTEPS >= 3
     v[j] = r < nrows ? *reinterpret_cast<const float4 *>(a.T + (row0 + r) * K + c) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   if (a.epi.R || a.epi.ca != 1.f || a.epi.T_out) {  // t' = ca * t + cb * R[row]
+    const float cb = a.epi.cb_dev ? *a.epi.cb_dev : a.epi.cb;  // uniform: one scalar load
 #pragma unroll
     for (int j = 0; j < NL; j++) {
       const int i = threadIdx.x + j * 256, r = i / (K / 4), c = (i % (K / 4)) * 4;
@@ -749,7 +766,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KSTEPS >= 3
       t4 = make_float4(t4.x * a.epi.ca, t4.y * a.epi.ca, t4.z * a.epi.ca, t4.w * a.epi.ca);
       if (a.epi.R) {
         const float4 rr = *reinterpret_cast<const float4 *>(a.epi.R + grow * K + c);
-        t4 = make_float4(t4.x + rr.x * a.epi.cb, t4.y + rr.y * a.epi.cb, t4.z + rr.z * a.epi.cb, t4.w + rr.w * a.epi.cb);
+        t4 = make_float4(t4.x + rr.x * cb, t4.y + rr.y * cb, t4.z + rr.z * cb, t4.w + rr.w * cb);
       }
       if (a.epi.T_out) *reinterpret_cast<float4 *>(a.epi.T_out + grow * K + c) = t4;
       v[j] = t4;
@@ -761,8 +778,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KSTEPS >= 3
     *reinterpret_cast<float4 *>(t + r * LD + c) = v[j];
   }
   __syncthreads();
+  Stamper none;
   panel_times_wt<KSTEPS>(t, nrows, a.F_out, a.Wlin, a.rowmap ? a.rowmap + row0 : nullptr, row0, a.Y,
-                         threadIdx.x, bv, a.epi.relu);
+                         threadIdx.x, bv, a.epi.relu, none);
 }
 
 // ---- weight gradient of the layer's linear: C[Fa, Fb] = A^T B over N rows --------------------
@@ -1057,13 +1075,14 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
       }
     }
     if (a.epi.R || a.epi.ca != 1.f) {  // t' = ca * t + cb * R[v]  (workgroup-uniform)
+      const float cb = a.epi.cb_dev ? *a.epi.cb_dev : a.epi.cb;
 #pragma unroll
       for (int i = 0; i < 4; i++)
         if (r0 + i < r1) {
           outr[i].mul(a.epi.ca);
           if (a.epi.R) {
             V rr = V::load(a.epi.R + (int64_t)prow[r0 + i] * F + col);
-            rr.mul(a.epi.cb);
+            rr.mul(cb);
             outr[i].add(rr);
           }
         }
@@ -1073,11 +1092,13 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
     float bv[BPre<TW / 4>::N];
     const LinSplit sp = lin_split(tid >> 6, a.F_out >> 4);
     if (sp.active && !(DBG && (a.debug & 512))) load_bfrag_pre<TW / 4>(a.Wlin, sp.nt_first, tid & 63, bv);
+    HG_STAMP(5);
     __syncthreads();  // every slot row has been read: the tile becomes the [rows][TW + 4] operand
 #pragma unroll
     for (int i = 0; i < 4; i++)
       if (r0 + i < r1) outr[i].store(tile + (r0 + i) * (TW + 4) + lcol);
     __syncthreads();
+    HG_STAMP(6);
     if (DBG && (a.debug & 256)) {  // ablation (timing only): no matrix work, the rows leave as they are
       const int q = min(a.F_out, TW) >> 2;
       for (int i = tid; i < nrows * q; i += 256) {
@@ -1095,7 +1116,10 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
             *reinterpret_cast<const float4 *>(tile + r * (TW + 4) + c);
       }
     }
-    panel_times_wt<TW / 4, LINW>(tile, nrows, a.F_out, a.Wlin, prow, 0, a.Y, tid, bv, a.epi.relu);
+    HG_STAMP(7);
+    panel_times_wt<TW / 4, LINW>(tile, nrows, a.F_out, a.Wlin, prow, 0, a.Y, tid, bv, a.epi.relu, stp);
+    HG_STAMP_FLUSH();
+    return;
   } else if (!(DBG && (a.debug & 8))) {  // ---- hop 2
     const int rpg = (nrows + NG - 1) / NG;
     const int r0 = min(g * rpg, nrows), r1 = min(r0 + rpg, nrows);
@@ -1730,7 +1754,7 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
   return staged ? launch_lds<fused_packed_kernel<LPR, VEC, 8, true, M, S, false, true, 256, false>>(grid, lds_l, stream, ad) \
                 : launch_lds<fused_packed_kernel<LPR, VEC, 8, true, M, S, false, true, 256, true>>(grid, lds_l, stream, ad)
 #ifdef HG_TUNING
-        if (t.fused_debug & (768 | 1))  // ablations of the matrix phase / the gathers (tools/linear_probe.py): diagnostic build only
+        if (t.fused_debug & (768 | 1 | 32))  // ablations of the matrix phase / the gathers (tools/linear_probe.py): diagnostic build only
           return launch_lds<fused_packed_kernel<LPR, VEC, 8, true, true, true, true, true>>(grid, lds_l, stream, ad);
 #endif
         switch (spec) {
@@ -1833,7 +1857,7 @@ bool fused_linear_ok(const FusedArgs &a) {
   const Tuning &t = tuning();
   const int lpr = a.F / 4;
   return (a.F == 32 || a.F == 64 || a.F == 128) && a.F_out > 0 && (a.F_out & 15) == 0 && t.fused_fast &&
-         !(t.fused_debug & 254) && a.x_bytes > 0 && a.nrows_x < (1 << 24) &&
+         !(t.fused_debug & 222) && a.x_bytes > 0 && a.nrows_x < (1 << 24) &&
          (!a.Xe_mat || (a.mat_bytes > 0 && a.nrows_mat < (1 << 24))) &&
          a.ng == 256 / lpr && a.rows_cap <= 4 * (256 / lpr) && a.rows_cap <= a.cap;
 }
@@ -1878,7 +1902,7 @@ hipError_t launch_fused(const FusedArgs &a, bool vec4, hipStream_t stream) {
 hipError_t read_stamps(unsigned long long *out, bool reset) {
   hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(hg_stamps), sizeof(hg_stamps));
   if (e == hipSuccess && reset) {
-    unsigned long long z[8] = {0};
+    unsigned long long z[16] = {0};
     e = hipMemcpyToSymbol(HIP_SYMBOL(hg_stamps), z, sizeof(z));
   }
   return e;

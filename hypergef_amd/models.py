@@ -59,9 +59,9 @@ class HyperGsysUinGINConv(nn.Module):
     def forward(self, X):
         if _variant_of(self.options) in ("auto", "pull", "fused") and ops.linear_fusion_pays(X.shape[1], self.W.weight.shape[0]):
             # (1 + eps) W(X) + Aggr(W(X)) = ((1 + eps) X + Aggr(X)) . W^T: the whole layer in one pass
-            # training: cb stays a tensor (eps is learned: its gradient flows through cb, and reading the value
-            # costs one device-to-host copy per step); without grad the value is read once per eps update and
-            # handed over as a Python float -- no sync in the forward, so the forward can be captured in a hipGraph
+            # training: cb stays a device tensor (eps is learned: its gradient flows through cb) and the kernel reads
+            # it from device memory -- no read-back, so the whole training step can be captured in a hipGraph;
+            # without grad the value is read once per eps update and handed over as a Python float (no extra kernel)
             if torch.is_grad_enabled() and self.eps.requires_grad:
                 cb = 1 + self.eps.reshape(())
             else:

@@ -319,9 +319,14 @@ class _AggrResLinear(torch.autograd.Function):
         degE, degV, W = _flat(degE), _flat(degV), _flat(W)
         N, F_in = node_feat.shape
         F_out = M.shape[0]
-        # cb is a Python float except where it is learned (UniGIN's 1 + eps): only then does reading
-        # it cost a device-to-host sync
-        cbf = float(cb) if R is not None else 0.0
+        # cb is a Python float except where it is learned (UniGIN's 1 + eps): then it stays on the device -- the
+        # kernel reads it there (hg_aggr_linear_res_dev_f32), nothing is read back, and the step can be captured
+        if R is None:
+            cbf = 0.0
+        elif isinstance(cb, torch.Tensor):
+            cbf = cb.detach().to(torch.float32).reshape(1).contiguous()
+        else:
+            cbf = float(cb)
         variant = opt.variant if opt.variant != "push_groups" else "auto"
         Md = M.detach().contiguous()
         Rd = None if R is None else R.detach().contiguous()

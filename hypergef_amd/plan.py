@@ -230,7 +230,9 @@ class Plan:
         """Y[N, F_out] = Aggr(X) . weight^T in one pass (hg_aggr_linear_f32); weight = nn.Linear.weight,
         [F_out, F_in]; packed = pack_linear(weight) if the caller keeps it across calls.
         With residual / ca / cb / relu / t_out: Y = act((ca * Aggr(X) + cb * residual) . weight^T) and
-        t_out receives the bracket (hg_aggr_linear_res_f32: one UniGCNII / UniGIN layer per pass).
+        t_out receives the bracket (hg_aggr_linear_res_f32: one UniGCNII / UniGIN layer per pass).  cb may be a
+        one-element float32 device tensor (a learned scalar such as UniGIN's 1 + eps): the kernel then reads it from
+        device memory (hg_aggr_linear_res_dev_f32) -- no read-back to the host, and a captured hipGraph sees its updates.
         Raises HgError(unsupported) for widths the MFMA epilogue does not take."""
         _check_feat(X, "node_feat")
         _check_feat(weight, "weight", device=X.device)
@@ -266,15 +268,22 @@ class Plan:
                     _check_feat(t, name, device=X.device)
                     if tuple(t.shape) != (self.N, F_in):
                         raise ValueError("%s must be [N, F_in]" % name)
+            if isinstance(cb, torch.Tensor):
+                _check_feat(cb, "cb", device=X.device)
+                if cb.numel() != 1:
+                    raise ValueError("a tensor cb must hold one element")
+                fn, cb_arg = _lib.lib().hg_aggr_linear_res_dev_f32, _ptr(cb)
+            else:
+                fn, cb_arg = _lib.lib().hg_aggr_linear_res_f32, float(cb)
             head = (self._h, F_in, F_out, _ptr(csrptr_t), _ptr(colind_t), _ptr(X), _ptr(degE), _ptr(degV),
-                    _ptr(W), _ptr(weight), _ptr(residual), float(ca), float(cb), 1 if relu else 0, _ptr(t_out), _ptr(Y))
+                    _ptr(W), _ptr(weight), _ptr(residual), float(ca), cb_arg, 1 if relu else 0, _ptr(t_out), _ptr(Y))
             stream = _stream_handle(X.device)
-            st = _lib.lib().hg_aggr_linear_res_f32(*head, _ptr(workspace), nbytes, _lib.VARIANTS[variant], stream)
+            st = fn(*head, _ptr(workspace), nbytes, _lib.VARIANTS[variant], stream)
             if st == _lib.HG_ERR_WORKSPACE and own_ws:  # stale cached size: see aggregate()
                 self.__dict__.setdefault("_ws_bytes", {}).pop(("lin", F_in), None)
                 workspace = torch.empty(max(self.linear_workspace_bytes(F_in), 256), dtype=torch.uint8, device=X.device)
                 nbytes = workspace.numel()
-                st = _lib.lib().hg_aggr_linear_res_f32(*head, _ptr(workspace), nbytes, _lib.VARIANTS[variant], stream)
+                st = fn(*head, _ptr(workspace), nbytes, _lib.VARIANTS[variant], stream)
             _lib.check(st)
         return Y
 

@@ -300,6 +300,15 @@ HG_API int hg_aggr_linear_res_f32(const hg_plan *plan, int32_t F_in, int32_t F_o
                                   const float *wfrag, const float *R, float ca, float cb, int32_t relu,
                                   float *T_out, float *Y, void *workspace, size_t workspace_bytes,
                                   int32_t variant, hg_stream_t stream);
+/* hg_aggr_linear_res_f32 with cb read from device memory when the kernel runs (cb_dev: one float, not NULL): for a
+ * LEARNED scalar -- UniGIN's 1 + eps (unigin.py:14,22) -- the caller neither reads the value back to the host
+ * (a device-to-host sync per layer and step) nor bakes it into a captured hipGraph. */
+HG_API int hg_aggr_linear_res_dev_f32(const hg_plan *plan, int32_t F_in, int32_t F_out,
+                                      const int32_t *csrptr_t, const int32_t *colind_t, const float *X,
+                                      const float *degE, const float *degV, const float *W,
+                                      const float *wfrag, const float *R, float ca, const float *cb_dev,
+                                      int32_t relu, float *T_out, float *Y, void *workspace,
+                                      size_t workspace_bytes, int32_t variant, hg_stream_t stream);
 /* The linear's weight gradient, C[F_a, F_b] = A^T B with A [nrows, F_a], B [nrows, F_b] row-major:
  * dWlin = dY^T T in the backward pass of the layers above (the contraction runs over the vertices).
  * Every element of A and B is read once, straight into fp32 MFMA operands; workgroups are reduced

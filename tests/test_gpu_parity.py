@@ -1077,11 +1077,14 @@ def test_options_are_per_call_and_follow_the_forward_into_backward(hg, oracle):
     assert torch.allclose(za, zb, rtol=1e-4, atol=1e-4) and ops.current_options() == ops.Options()
 
 
-def test_training_step_replays_as_a_hipgraph(hg):
-    """A whole training step of the 2-layer HGNN (forward through the fused aggregation + linear, nll loss,
+@pytest.mark.parametrize("model", ["HGNN", "UniGIN"])
+def test_training_step_replays_as_a_hipgraph(hg, model):
+    """A whole training step of the 2-layer HGNN / UniGIN (forward through the fused aggregation + linear, nll loss,
     backward through the library's aggregation / wgrad kernels, capturable Adam) recorded into one hipGraph:
     K replays leave the parameters where K eager steps leave them (no dropout, deterministic kernels).  Nothing
-    in the library may allocate plan state, synchronise or read back during the captured step."""
+    in the library may allocate plan state, synchronise or read back during the captured step -- UniGIN's learned
+    1 + eps included: the layer kernel reads it from device memory (hg_aggr_linear_res_dev_f32), so the replays see
+    the value Adam wrote in the step before."""
     import types
     import torch.nn.functional as Fn
     from hypergef_amd import models, plan as planmod
@@ -1091,7 +1094,7 @@ def test_training_step_replays_as_a_hipgraph(hg):
     X = torch.randn(inc.N, nfeat, device=DEV, generator=torch.Generator(DEV).manual_seed(3))
     y = torch.randint(0, ncls, (inc.N,), device=DEV, generator=torch.Generator(DEV).manual_seed(4))
     idx = torch.arange(0, inc.N, 2, device=DEV)
-    args = types.SimpleNamespace(model="HGNN", activation="relu", input_drop=0.0, dropout=0.0, backend="hgsys")
+    args = types.SimpleNamespace(model=model, activation="relu", input_drop=0.0, dropout=0.0, backend="hgsys")
 
     def make():
         torch.manual_seed(11)
@@ -1130,7 +1133,36 @@ def test_training_step_replays_as_a_hipgraph(hg):
     for pa, pb in zip(ma.parameters(), mb.parameters()):
         assert torch.allclose(pa, pb, rtol=1e-5, atol=1e-6), float((pa - pb).abs().max())
     assert abs(float(la) - float(lb)) <= 1e-5 * max(1.0, abs(float(la)))
+    if model == "UniGIN":  # eps was learned under the replays: it moved, and by as much as in the eager steps
+        eps = [p for n, p in mb.named_parameters() if n.endswith("eps")]
+        assert eps and all(float(e.abs()) > 0 for e in eps)
     planmod.clear_pack_cache()
+
+
+def test_layer_scalar_from_device_memory(hg, oracle):
+    """hg_aggr_linear_res_dev_f32: cb read from a device scalar gives the bits of hg_aggr_linear_res_f32 with the same
+    value on the host, on the fused path and on the pull path (standalone rows kernel); a later write to the scalar is
+    seen by the next call without any re-binding."""
+    from hypergef_amd.plan import Plan
+    inc = _make("pubmed")
+    F = 64
+    rng = np.random.default_rng(31)
+    X = _dev(rng.standard_normal((inc.N, F)).astype(np.float32))
+    Wl = _dev((rng.standard_normal((F, F)) / 8).astype(np.float32))
+    ptr, ind = _dev(inc.csrptr), _dev(inc.colind)
+    plan = Plan.from_tensors(inc.N, ptr, ind)
+    cb = torch.tensor([1.25], device=DEV)
+    for variant in ("fused", "pull"):
+        y_host = plan.aggregate_linear(ptr, ind, X, Wl, variant=variant, residual=X, ca=1.0, cb=1.25, relu=True)
+        y_dev = plan.aggregate_linear(ptr, ind, X, Wl, variant=variant, residual=X, ca=1.0, cb=cb, relu=True)
+        assert torch.equal(y_host, y_dev), variant
+        cb.fill_(0.5)
+        y2 = plan.aggregate_linear(ptr, ind, X, Wl, variant=variant, residual=X, ca=1.0, cb=cb, relu=True)
+        assert torch.equal(y2, plan.aggregate_linear(ptr, ind, X, Wl, variant=variant, residual=X, ca=1.0, cb=0.5, relu=True))
+        assert not torch.equal(y2, y_host)
+        cb.fill_(1.25)
+    with pytest.raises(ValueError):
+        plan.aggregate_linear(ptr, ind, X, Wl, residual=X, cb=torch.ones(2, device=DEV))
 
 
 def test_rccl_branches_execute_at_world_size_one(hg, tmp_path):

@@ -50,6 +50,10 @@ def parse():
                    help="inference as one hipGraph replay per forward (launch-bound models: a dataset-sized hypergraph)")
     p.add_argument("--graph-train", action="store_true",
                    help="the training step (forward, loss, backward, Adam) as one hipGraph replay per epoch")
+    p.add_argument("--no-graph", action="store_true",
+                   help="never capture.  Default: a model over ONE launch-bound hypergraph (at most 2^18 incidences, one "
+                        "GPU) runs its training step and its forward as hipGraph replays, both backends alike -- eager, "
+                        "such an epoch is ~100 launches of host latency; the eager figures are printed beside the replays")
     p.add_argument("--output", type=str, default=None)
     return p.parse_args()
 
@@ -89,9 +93,14 @@ def main():
     if world > 1:
         model = torch.nn.parallel.DistributedDataParallel(
             model, device_ids=[dev.index] if dev.type == "cuda" else None)
-    graph_train = args.graph_train and dev.type == "cuda" and world == 1
-    # capturable: Adam's step counters live on the device, so the update can be recorded into a hipGraph
-    opti = optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.wd, capturable=graph_train)
+    # One dataset-sized hypergraph is launch-bound end to end (HGNN on cora: a forward is 102 us of mostly host launch
+    # latency, 26 us as a replay): capture is the default there, for both backends; --no-graph opts out.
+    launch_bound = dev.type == "cuda" and world == 1 and inc.nnz <= (1 << 18) and not args.no_graph and not args.profile
+    graph_train = dev.type == "cuda" and world == 1 and not args.no_graph and (args.graph_train or launch_bound)
+    graph_infer = dev.type == "cuda" and not args.no_graph and (args.graph or launch_bound)
+    # the eager epochs run the plain Adam (what a run without capture runs); the captured section gets a capturable
+    # twin (step counters on the device) carrying the same state
+    opti = optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.wd)
     if rank == 0:
         print(f"Total Epochs: {args.epochs}")
         print(f"total_params:{sum(p.numel() for p in model.parameters() if p.requires_grad)}")
@@ -128,7 +137,16 @@ def main():
         # those counters (a packed weight cached under (address, version) would go stale).
         from hypergef_amd import plan as planmod
         eager_time = trainTime
+        # the captured section trains on (warm-up, capture, timed replays): snapshot what the eager epochs produced, so
+        # that the evaluation below sees the model after exactly 10 + epochs steps, as in a run without capture
+        snap = [p.detach().clone() for p in model.parameters()]
+        eager_opti, eager_loss = opti, loss
         try:
+            sd = eager_opti.state_dict()
+            for grp in sd["param_groups"]:
+                grp["capturable"] = True
+            opti = optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.wd, capturable=True)
+            opti.load_state_dict(sd)
             planmod.clear_pack_cache()
             side = torch.cuda.Stream(dev)
             side.wait_stream(torch.cuda.current_stream(dev))
@@ -154,15 +172,22 @@ def main():
                 g.replay()
             sync()
             trainTime = (time.time() - start) / args.epochs
-            loss = static_loss.detach().clone()
-            planmod.clear_pack_cache()
+            replay_loss = static_loss.detach().clone()
+            assert torch.isfinite(replay_loss), "training diverged under replay"
             if rank == 0:
-                print(f"backend {args.backend}: avg epoch time {trainTime:.6f} as a hipGraph replay (eager {eager_time:.6f}), "
-                      f"loss {loss.item():.4f}")
-        except Exception as exc:  # e.g. UniGIN's learned 1 + eps is read back on the host in training: not capturable
+                print(f"backend {args.backend}: avg epoch time {trainTime:.6f} as a hipGraph replay (eager, plain Adam: "
+                      f"{eager_time:.6f}), loss after the replays {replay_loss.item():.4f}")
+        except Exception as exc:
             sync()
             if rank == 0:
                 print("graph capture of the training step failed (%s: %s); eager figure kept" % (type(exc).__name__, str(exc)[:200]))
+        finally:
+            sync()
+            with torch.no_grad():
+                for p, q in zip(model.parameters(), snap):
+                    p.copy_(q)
+            opti, loss = eager_opti, eager_loss
+            planmod.clear_pack_cache()  # the weights changed behind torch's version counters during the replays
     if args.profile:
         print(f"epoch time: {trainTime * args.epochs:.4f}")
         return
@@ -174,7 +199,7 @@ def main():
             Z = model(X)
     sync()
     inferenceTime = (time.time() - start) / args.epochs
-    if args.graph and dev.type == "cuda":
+    if graph_infer:
         # The forward of a small model is a chain of launch-bound kernels: capture it once (every plan, bound
         # scale set and packed weight exists after the eager passes above) and replay the graph per forward.
         eager = Z.clone()

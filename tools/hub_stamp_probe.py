@@ -17,7 +17,7 @@ info = plan.prepare(F)
 Y = torch.empty(inc.N, F, device=dev)
 ws = torch.empty(max(plan.workspace_bytes(F), 256), dtype=torch.uint8, device=dev)
 L = _lib.lib()
-buf = (ctypes.c_ulonglong * 8)()
+buf = (ctypes.c_ulonglong * 16)()
 for _ in range(3):
     plan.aggregate(ptr, ind, X, out=Y, workspace=ws, variant="fused")
 torch.cuda.synchronize()
