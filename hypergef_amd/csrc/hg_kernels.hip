@@ -341,7 +341,7 @@ struct Stamper {
 };
 #define HG_STAMP_INIT(cond) \
   Stamper stp;              \
-  stp.init(((a.debug & 32) != 0) && (cond))
+  stp.init(((a.debug & 32) != 0) && (cond) && (blockIdx.x & 63) == 5)  /* one workgroup in 64: the flush's atomics stay out of the way */
 #else
 struct Stamper {
   __device__ __forceinline__ void init(bool) {}
@@ -653,6 +653,117 @@ __device__ __forceinline__ void panel_times_wt_staged_chunked(float *t, int nrow
   HG_STAMP(11);
 }
 
+// K = 128, staged-only instances (round 4).  The chunked phase above keeps ONE chunk of 8 k-steps in flight behind the
+// chunk that feeds the matrix pipe: 16 MFMAs = 512 cycles of cover for an L2 round trip of 1-2 thousand cycles under
+// load, eight times per panel and wave -- phase stamps put 41 % of a workgroup's life into this loop, four times the
+// matrix pipe's own time for it.  Here the wave holds a whole column tile of B (32 fragment registers, loaded before hop 2
+// and the barriers that precede the phase), and its second column tile streams into those registers chunk by chunk as
+// the first tile's k-steps retire: every load has a whole column tile's MFMAs (2048 cycles and more) to land.  The
+// registers come for free: at K = 128 the LDS tile holds occupancy to 5 workgroups per CU, i.e. 96 VGPRs per lane.
+template <int KSTEPS, int NPW, int NRT>
+__device__ __forceinline__ void mfma_rows_ring(const float *ta, int tstep, const float *Wlin, const LinSplit &sp, int NT,
+                                               int lane, float (&b)[KSTEPS], hg_f4 *acc) {
+  constexpr int RPN = 4 / NPW, CH = 8, NCH = KSTEPS / CH;
+#pragma unroll
+  for (int ni = 0; ni < NPW; ni++) {
+    const int nt = sp.nt_first + ni * sp.nt_step;
+    if (nt < NT) {  // wave-uniform
+      const int nt2 = sp.nt_first + (ni + 1) * sp.nt_step;
+      const bool more = ni + 1 < NPW && nt2 < NT;
+      float a0[NRT], a1[NRT], a2[NRT];
+#pragma unroll
+      for (int j = 0; j < NRT; j++) {
+        a0[j] = ta[j * tstep];
+        a1[j] = ta[j * tstep + 4];
+      }
+#pragma unroll
+      for (int c = 0; c < NCH; c++) {
+#pragma unroll
+        for (int k8 = 0; k8 < CH; k8++) {
+          const int ks = c * CH + k8;
+          if (ks + 2 < KSTEPS) {
+#pragma unroll
+            for (int j = 0; j < NRT; j++) a2[j] = ta[j * tstep + (ks + 2) * 4];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < NRT; j++)
+            acc[ni * RPN + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b[ks], acc[ni * RPN + j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < NRT; j++) {
+            a0[j] = a1[j];
+            a1[j] = a2[j];
+          }
+        }
+        if (more) {  // this chunk's registers are free: the next column tile's chunk c lands in them
+          const float4 *w = reinterpret_cast<const float4 *>(Wlin) + ((int64_t)nt2 * (KSTEPS / 4) + 2 * c) * 64 + lane;
+          const float4 f0 = w[0], f1 = w[64];
+          b[c * CH + 0] = f0.x; b[c * CH + 1] = f0.y; b[c * CH + 2] = f0.z; b[c * CH + 3] = f0.w;
+          b[c * CH + 4] = f1.x; b[c * CH + 5] = f1.y; b[c * CH + 6] = f1.z; b[c * CH + 7] = f1.w;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+}
+
+// The staged form (see panel_times_wt_staged) on the ring matrix phase.  b: the wave's whole first column tile.
+template <int KSTEPS, int NPW>
+__device__ __forceinline__ void panel_times_wt_staged_ring(float *t, int nrows, int F_out, const float *Wlin,
+                                                           const int32_t *rowmap, float *Y, int tid, float (&b)[KSTEPS],
+                                                           int relu, Stamper &stp) {
+  constexpr int K = KSTEPS * 4, LD = K + 4, RPN = 4 / NPW;
+  const int lane = tid & 63;
+  const int NT = F_out >> 4, RT = (nrows + 15) >> 4;
+  const LinSplit sp = lin_split(tid >> 6, NT);
+  hg_f4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) acc[j] = hg_f4{0.f, 0.f, 0.f, 0.f};
+  int nrt = 0;
+  if (sp.active) {
+    nrt = min(RPN, max(0, (RT - sp.rt_first + sp.rt_step - 1) / sp.rt_step));
+    const float *ta = t + (sp.rt_first * 16 + (lane & 15)) * LD + (lane >> 4);
+    const int tstep = sp.rt_step * 16 * LD;
+    switch (nrt) {  // wave-uniform
+      case 4: if constexpr (RPN >= 4) mfma_rows_ring<KSTEPS, NPW, 4>(ta, tstep, Wlin, sp, NT, lane, b, acc); break;
+      case 3: if constexpr (RPN >= 4) mfma_rows_ring<KSTEPS, NPW, 3>(ta, tstep, Wlin, sp, NT, lane, b, acc); break;
+      case 2: if constexpr (RPN >= 2) mfma_rows_ring<KSTEPS, NPW, 2>(ta, tstep, Wlin, sp, NT, lane, b, acc); break;
+      case 1: mfma_rows_ring<KSTEPS, NPW, 1>(ta, tstep, Wlin, sp, NT, lane, b, acc); break;
+      default: break;
+    }
+  }
+  HG_STAMP(8);
+  __syncthreads();  // every wave has read its A fragments: the rows can be overwritten
+  HG_STAMP(9);
+  if (sp.active) {
+#pragma unroll
+    for (int ni = 0; ni < NPW; ni++) {
+      const int nt = sp.nt_first + ni * sp.nt_step;
+      if (nt < NT) {
+#pragma unroll
+        for (int j = 0; j < RPN; j++)
+          if (j < nrt) {
+            float *d = t + ((sp.rt_first + j * sp.rt_step) * 16 + 4 * (lane >> 4)) * LD + nt * 16 + (lane & 15);
+#pragma unroll
+            for (int i = 0; i < 4; i++) d[i * LD] = acc[ni * RPN + j][i];
+          }
+      }
+    }
+  }
+  __syncthreads();
+  HG_STAMP(10);
+  const int q = F_out >> 2;  // float4 pieces per row
+  for (int i = tid; i < nrows * q; i += 256) {
+    const int r = i / q, c = (i - r * q) * 4;
+    float4 o = *reinterpret_cast<const float4 *>(t + r * LD + c);
+    if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+    if (HG_Y_NT) Vec<4>{o}.store_nt(Y + (int64_t)rowmap[r] * F_out + c);
+    else *reinterpret_cast<float4 *>(Y + (int64_t)rowmap[r] * F_out + c) = o;
+  }
+  HG_STAMP(11);
+}
+
 // WIDE = false: the caller guarantees the staged form applies (F_out <= K and few enough row tiles); the direct form
 // for wider outputs is then not compiled in -- its registers would set the budget of the whole kernel.
 template <int KSTEPS, bool WIDE = true>
@@ -894,6 +1005,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *partial,
 #ifndef HG_LIN_WAVES_STAGED
 #define HG_LIN_WAVES_STAGED 8
 #endif
+// K = 128 staged-only instances: the LDS tile of the epilogue's schedule (48 slots x 132 floats + record) allows five
+// workgroups per CU anyway; the register budget that goes with five waves per SIMD holds a whole B column tile
+#ifndef HG_LIN_WAVES_STAGED32
+#define HG_LIN_WAVES_STAGED32 5
+#endif
 typedef unsigned hg_u4 __attribute__((ext_vector_type(4)));
 typedef int hg_i4 __attribute__((ext_vector_type(4)));
 
@@ -916,7 +1032,7 @@ typedef int hg_i4 __attribute__((ext_vector_type(4)));
 // only and fit 8 waves per SIMD without spills; the direct form's registers used to set the budget of every LIN
 // instance (natural demand 85-92 VGPRs, 5-6 waves).
 template <int LPR, int VEC, int U, bool FAST, bool MAT, bool SCALED, bool DBG, bool LIN = false, int BS = 256, bool LINW = true>
-__global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW ? HG_LIN_WAVES_STAGED : LPR >= 32 ? HG_LIN_WAVES32 : LPR == 16 ? HG_LIN_WAVES16 : HG_LIN_WAVES8) : 1, 8))) void fused_packed_kernel(const FusedArgs a) {
+__global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW ? (LPR >= 32 ? HG_LIN_WAVES_STAGED32 : HG_LIN_WAVES_STAGED) : LPR >= 32 ? HG_LIN_WAVES32 : LPR == 16 ? HG_LIN_WAVES16 : HG_LIN_WAVES8) : 1, 8))) void fused_packed_kernel(const FusedArgs a) {
   static_assert(!LIN || BS == 256, "the linear epilogue is written for four waves");
   constexpr int NG = BS / LPR;
   constexpr int TW = LPR * VEC;
@@ -1061,6 +1177,12 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
   __syncthreads();
   HG_STAMP(4);
   if constexpr (LIN) {  // ---- hop 2 into registers, then rows * Wlin^T on the matrix cores
+    // The B fragments of this wave's first column tile are issued after hop 2 and fly across the two barriers that follow
+    // (before hop 2 they would sit in registers through it: spills).  RING (K = 128, staged only): the whole column tile
+    // (mfma_rows_ring); the others: what BPre says.
+    constexpr bool RING = !LINW && TW / 4 >= 32;
+    float bv[RING ? TW / 4 : BPre<TW / 4>::N];
+    const LinSplit sp = lin_split(tid >> 6, a.F_out >> 4);
     const int rpg = (nrows + NG - 1) / NG;  // <= 4 (launcher)
     const int r0 = min(g * rpg, nrows), r1 = min(r0 + rpg, nrows);
     V outr[4];
@@ -1087,11 +1209,10 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
           }
         }
     }
-    // the B fragments of this wave's first column tile: in flight across the two barriers below
-    // (issued before hop 2 they would hold K/4 more registers through it: 78 instead of 64 VGPRs)
-    float bv[BPre<TW / 4>::N];
-    const LinSplit sp = lin_split(tid >> 6, a.F_out >> 4);
-    if (sp.active && !(DBG && (a.debug & 512))) load_bfrag_pre<TW / 4>(a.Wlin, sp.nt_first, tid & 63, bv);
+    if (sp.active && !(DBG && (a.debug & 512))) {
+      if constexpr (RING) load_bfrag<TW / 4>(a.Wlin, sp.nt_first, tid & 63, bv);
+      else load_bfrag_pre<TW / 4>(a.Wlin, sp.nt_first, tid & 63, bv);
+    }
     HG_STAMP(5);
     __syncthreads();  // every slot row has been read: the tile becomes the [rows][TW + 4] operand
 #pragma unroll
@@ -1117,7 +1238,12 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
       }
     }
     HG_STAMP(7);
-    panel_times_wt<TW / 4, LINW>(tile, nrows, a.F_out, a.Wlin, prow, 0, a.Y, tid, bv, a.epi.relu, stp);
+    if constexpr (RING) {
+      if (a.F_out > 64) panel_times_wt_staged_ring<TW / 4, 2>(tile, nrows, a.F_out, a.Wlin, prow, a.Y, tid, bv, a.epi.relu, stp);
+      else panel_times_wt_staged_ring<TW / 4, 1>(tile, nrows, a.F_out, a.Wlin, prow, a.Y, tid, bv, a.epi.relu, stp);
+    } else {
+      panel_times_wt<TW / 4, LINW>(tile, nrows, a.F_out, a.Wlin, prow, 0, a.Y, tid, bv, a.epi.relu, stp);
+    }
     HG_STAMP_FLUSH();
     return;
   } else if (!(DBG && (a.debug & 8))) {  // ---- hop 2
@@ -1352,6 +1478,7 @@ __global__ __launch_bounds__(1024) void hub_pass_kernel(const HubArgs a) {
       __syncthreads();
       if (g == 0) {
         V tot = V::zero();
+#pragma unroll 8  // left alone the compiler unrolls all NG (128 at F = 32) tile reads at once: 44-84 bytes of scratch per lane
         for (int q = 0; q < NG; q++) tot.add(V::load(tile + q * TW + lcol));
         if (col_ok) tot.store(a.partial + (int64_t)(a.hslot0[h] + w) * F + col);
       }
