@@ -85,6 +85,7 @@ struct HubArgs {
   const int32_t *wg_first;  // [nwg + 1] rounds of each workgroup
   const int32_t *vslot0;    // [ng * R] first partial row of each virtual row, -1 = unused
   int32_t nwg, ng, cap, max_rec_words;
+  int32_t bs = 1024;        // threads per workgroup the records were packed for (ng = bs / lanes per row)
   const float *X, *Xe_mat, *degE, *W;
   float *partial;
   int32_t F;

@@ -722,12 +722,12 @@ __device__ __forceinline__ void panel_times_wt_staged_ring(float *t, int nrows, 
   for (int j = 0; j < 4; j++) acc[j] = hg_f4{0.f, 0.f, 0.f, 0.f};
   int nrt = 0;
   if (sp.active) {
-    nrt = min(RPN, max(0, (RT - sp.rt_first + sp.rt_step - 1) / sp.rt_step));
+    nrt = min(min(RPN, 2), max(0, (RT - sp.rt_first + sp.rt_step - 1) / sp.rt_step));
     const float *ta = t + (sp.rt_first * 16 + (lane & 15)) * LD + (lane >> 4);
     const int tstep = sp.rt_step * 16 * LD;
+    // K = 128 panels hold at most 4 rows per lane group x 8 lane groups = two row tiles (launcher): nrt <= 2.  The three-
+    // and four-tile forms are not compiled in -- their A-fragment registers were what spilled at this budget.
     switch (nrt) {  // wave-uniform
-      case 4: if constexpr (RPN >= 4) mfma_rows_ring<KSTEPS, NPW, 4>(ta, tstep, Wlin, sp, NT, lane, b, acc); break;
-      case 3: if constexpr (RPN >= 4) mfma_rows_ring<KSTEPS, NPW, 3>(ta, tstep, Wlin, sp, NT, lane, b, acc); break;
       case 2: if constexpr (RPN >= 2) mfma_rows_ring<KSTEPS, NPW, 2>(ta, tstep, Wlin, sp, NT, lane, b, acc); break;
       case 1: mfma_rows_ring<KSTEPS, NPW, 1>(ta, tstep, Wlin, sp, NT, lane, b, acc); break;
       default: break;
@@ -1010,6 +1010,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *partial,
 #ifndef HG_LIN_WAVES_STAGED32
 #define HG_LIN_WAVES_STAGED32 5
 #endif
+#ifndef HG_LIN_U32
+#define HG_LIN_U32 12  // row gathers in flight per lane, K = 128 staged instances: two batches cover the 24 steps of a 48-slot panel (16 spills at 96 VGPRs)
+#endif
 typedef unsigned hg_u4 __attribute__((ext_vector_type(4)));
 typedef int hg_i4 __attribute__((ext_vector_type(4)));
 
@@ -1186,15 +1189,36 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
     const int rpg = (nrows + NG - 1) / NG;  // <= 4 (launcher)
     const int r0 = min(g * rpg, nrows), r1 = min(r0 + rpg, nrows);
     V outr[4];
+    // The lane group's (up to) four rows are walked together: their list ends in one LDS round trip, then per step the
+    // four slot ids and the four tile rows in flight at once -- row after row the same reads are a chain of some twenty
+    // dependent LDS latencies, 18 % of a workgroup's life at F = 128 (phase stamps).  Each row still adds its slots in
+    // list order: same bits.  The trip count is the wave's longest list (wave-uniform); a step past a row's end re-reads
+    // slot 0 and is not added.
+    int pb_[4], n_[4], len = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       outr[i] = V::zero();
       const int r = r0 + i;
-      if (r < r1) {
-        const int pb = r ? pend[r - 1] : 0, pe = pend[r];
-        for (int p = pb; p < pe; p++) outr[i].add(V::load(tile + (int)pvs[p] * TW + lcol));
-        if (a.degV && pe > pb) outr[i].mul(sdeg[r]);
-      }
+      const bool ok = r < r1;
+      pb_[i] = (ok && r) ? (int)pend[r - 1] : 0;
+      n_[i] = ok ? (int)pend[r] - pb_[i] : 0;
+      len = max(len, n_[i]);
+    }
+    for (int k = 0; __builtin_amdgcn_ballot_w64(k < len) != 0; k++) {
+      int sidx[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) sidx[i] = k < n_[i] ? (int)pvs[pb_[i] + k] : 0;
+      V t[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) t[i] = V::load(tile + sidx[i] * TW + lcol);
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        if (k < n_[i]) outr[i].add(t[i]);
+    }
+    if (a.degV) {
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        if (n_[i] > 0) outr[i].mul(sdeg[r0 + i]);
     }
     if (a.epi.R || a.epi.ca != 1.f) {  // t' = ca * t + cb * R[v]  (workgroup-uniform)
       const float cb = a.epi.cb_dev ? *a.epi.cb_dev : a.epi.cb;
@@ -1292,9 +1316,9 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
 #else
 #define HG_HUB_ABLATE(bit) false
 #endif
-template <int LPR, int VEC, int U, bool MAT, bool SCALED, bool HEAVY>
-__global__ __launch_bounds__(1024) void hub_pass_kernel(const HubArgs a) {
-  constexpr int BS = 1024, NG = BS / LPR, TW = LPR * VEC, R = kHubRows, NH = HEAVY ? kHubHeavy : 1;
+template <int LPR, int VEC, int U, bool MAT, bool SCALED, bool HEAVY, int BS = 1024>
+__global__ __launch_bounds__(BS) void hub_pass_kernel(const HubArgs a) {
+  constexpr int NG = BS / LPR, TW = LPR * VEC, R = kHubRows, NH = HEAVY ? kHubHeavy : 1;
   using V = Vec<VEC>;
   extern __shared__ int32_t smem[];
   const int tid = threadIdx.x;
@@ -1326,7 +1350,7 @@ __global__ __launch_bounds__(1024) void hub_pass_kernel(const HubArgs a) {
   HG_STAMP_INIT(true);
   // A record is at most NPRE * 16 KB: each thread carries NPRE dwordx4 of the NEXT round's record
   // through hop 1, so the copy's round trip hides behind the row gathers.
-  constexpr int NPRE = 2;
+  constexpr int NPRE = (6144 * 4 + BS * 16 - 1) / (BS * 16);  // a record is at most 6144 words (kHubRecWords, hg_fused.cpp)
   hg_i4 pre[NPRE];
   auto fetch = [&](int rd) {
     const HubRec rt = a.rec_tab[rd];
@@ -1800,14 +1824,27 @@ size_t hub_pass_lds_bytes(int32_t cap, int32_t row_floats, int32_t max_rec_words
 template <int LPR>
 static hipError_t launch_hub_t(const HubArgs &a, hipStream_t stream) {
   constexpr int TW = LPR * 4;
-  if (a.ng != 1024 / LPR) return hipErrorInvalidValue;  // records were packed for another lane layout
+  if (a.ng != a.bs / LPR || (a.bs != 1024 && a.bs != 512)) return hipErrorInvalidValue;  // records were packed for another lane layout
   const bool fast = a.x_bytes > 0 && a.nrows_x < (1 << 24) && a.F < (1 << 22) &&
                     (!a.Xe_mat || (a.mat_bytes > 0 && a.nrows_mat < (1 << 24)));
   if (!fast) return hipErrorInvalidValue;  // the plan builds a hub pass only for buffer-addressable tables
   const dim3 grid(a.nwg, (a.F + TW - 1) / TW);
   const size_t lds = hub_pass_lds_bytes(a.cap, TW, a.max_rec_words);
-  if (a.cap < 1024 / LPR) return hipErrorInvalidValue;  // the end-of-launch reduction parks one row per lane group in the tile
+  if (a.cap < a.bs / LPR) return hipErrorInvalidValue;  // the end-of-launch reduction parks one row per lane group in the tile
   const int spec = (a.Xe_mat ? 1 : 0) | ((a.degE || a.W) ? 2 : 0) | (a.n_heavy > 0 ? 4 : 0);
+#ifdef HG_TUNING
+  // diagnostic build: 512-thread workgroups (half the register file, so panel workgroups fit beside a hub workgroup),
+  // compiled for the power-law bench configuration's lane layout only
+  if (a.bs == 512) {
+    if constexpr (LPR == 16) {
+      if (spec == 5) return launch_lds<hub_pass_kernel<LPR, 4, 4, true, false, true, 512>, 512>(grid, lds, stream, a);
+      if (spec == 7) return launch_lds<hub_pass_kernel<LPR, 4, 4, true, true, true, 512>, 512>(grid, lds, stream, a);
+    }
+    return hipErrorInvalidValue;
+  }
+#else
+  if (a.bs != 1024) return hipErrorInvalidValue;
+#endif
 #define HG_HUB(M, S, H) return launch_lds<hub_pass_kernel<LPR, 4, 4, M, S, H>, 1024>(grid, lds, stream, a)
   switch (spec) {
     case 0: HG_HUB(false, false, false);
@@ -1877,8 +1914,11 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
         // the staged matrix phase alone serves this call (as panel_times_wt decides per panel, for the fullest panel)
         const int nt_all = a.F_out >> 4, nwr = nt_all >= 3 ? 1 : 4 / nt_all;
         const bool staged = a.F_out <= TW && (((a.rows_cap + 15) >> 4) + nwr - 1) / nwr <= (a.F_out > 64 ? 2 : 4);
+        // K = 128, staged: the LDS tile already holds occupancy to five workgroups per CU, so the registers for twelve row
+        // gathers in flight per lane cost nothing there (a panel's hop 1 is then two dependent batches instead of three)
+        constexpr int UL = LPR >= 32 ? HG_LIN_U32 : 8;
 #define HG_PKL(M, S)                                                                                                          \
-  return staged ? launch_lds<fused_packed_kernel<LPR, VEC, 8, true, M, S, false, true, 256, false>>(grid, lds_l, stream, ad) \
+  return staged ? launch_lds<fused_packed_kernel<LPR, VEC, UL, true, M, S, false, true, 256, false>>(grid, lds_l, stream, ad) \
                 : launch_lds<fused_packed_kernel<LPR, VEC, 8, true, M, S, false, true, 256, true>>(grid, lds_l, stream, ad)
 #ifdef HG_TUNING
         if (t.fused_debug & (768 | 1 | 32))  // ablations of the matrix phase / the gathers (tools/linear_probe.py): diagnostic build only
