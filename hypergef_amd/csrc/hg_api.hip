@@ -182,7 +182,9 @@ double small_graph_cost(const hg::FusedSched &f) {
 // the slots do (pubmed-shape, F = 128: 32 slots hold 24 rows on average; 48 hold the 32).  lin_caps() returns false
 // where the default schedule is already that shape (F = 32: 128 rows of 128 slots) or the caller fixed the tile.
 bool lin_caps(const hg_plan *p, int32_t F, bool vec4, int32_t &cap, int32_t &mem_cap, int32_t &rows_cap) {
-  if (!vec4 || (F != 64 && F != 128) || !p->opts.fused_tile_auto || p->opts.fused_steps > 0 || p->nnz <= (1 << 18)) return false;
+  // F = 128 only: at F = 64 the default panels hold 53 of their 64 rows already, and every larger tile lost there
+  // (cora x1024 64 -> 64: 0.463 ms default, 0.469-0.475 with 80 slots, 0.485-0.492 with 96; profiles/r04_experiments.md)
+  if (!vec4 || F != 128 || !p->opts.fused_tile_auto || p->opts.fused_steps > 0 || p->nnz <= (1 << 18)) return false;
   int pct = 150;
 #ifdef HG_TUNING
   if (const char *e = getenv("HG_LIN_SLOTS_PCT")) pct = atoi(e);  // diagnostic build: 0 = the default schedule
@@ -194,8 +196,11 @@ bool lin_caps(const hg_plan *p, int32_t F, bool vec4, int32_t &cap, int32_t &mem
 #ifdef HG_TUNING
   if (const char *e = getenv("HG_LIN_ROWS_CAP")) rows_cap = std::max(16, std::min(rows_cap, atoi(e) / 16 * 16));
 #endif
-  cap = std::max(cap, (rows_cap * pct / 100 + 15) / 16 * 16);
+  cap = std::max(cap, (rows_cap * pct / 100 + 7) / 8 * 8);
   mem_cap = cap * 4;
+#ifdef HG_TUNING
+  if (const char *e = getenv("HG_LIN_STEPS")) mem_cap = std::max(p->opts.t_big, std::min(mem_cap, atoi(e) * ng));  // whole batches of row loads
+#endif
   return true;
 }
 
@@ -881,8 +886,37 @@ __attribute__((visibility("default"))) int hg_debug_read_stamps(unsigned long lo
   return hg::read_stamps(out16, reset != 0) == hipSuccess ? HG_OK : HG_ERR_HIP;
 }
 
+// Diagnostic only (not declared in hg_aggr.h): sustained rate of v_mfma_f32_16x16x4_f32 from registers.  out3 = {seconds,
+// TFLOP/s, shader-clock ticks (s_memtime) of one wave}; blocks x 4 waves, iters x 16 MFMAs per wave.
+__attribute__((visibility("default"))) int hg_debug_mfma_rate(int32_t blocks, int32_t iters, double *out3) {
+  float *sink = nullptr;
+  unsigned long long *ticks = nullptr, h_ticks = 0;
+  HG_HIP(hipMalloc(reinterpret_cast<void **>(&sink), 16));
+  HG_HIP(hipMalloc(reinterpret_cast<void **>(&ticks), 8));
+  hipEvent_t e0, e1;
+  HG_HIP(hipEventCreate(&e0));
+  HG_HIP(hipEventCreate(&e1));
+  HG_HIP(hg::launch_mfma_rate(blocks, iters, sink, ticks, nullptr));  // warm-up
+  HG_HIP(hipEventRecord(e0, nullptr));
+  HG_HIP(hg::launch_mfma_rate(blocks, iters, sink, ticks, nullptr));
+  HG_HIP(hipEventRecord(e1, nullptr));
+  HG_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HG_HIP(hipEventElapsedTime(&ms, e0, e1));
+  HG_HIP(hipMemcpy(&h_ticks, ticks, 8, hipMemcpyDeviceToHost));
+  (void)hipFree(sink);
+  (void)hipFree(ticks);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  const double flop = (double)blocks * 4.0 * iters * 16.0 * 2048.0;
+  out3[0] = ms * 1e-3;
+  out3[1] = flop / (ms * 1e-3) / 1e12;
+  out3[2] = (double)h_ticks;
+  return HG_OK;
+}
+
 // Diagnostic only (not declared in hg_aggr.h): shape of the fused schedule of width F -- lin != 0: the linear epilogue's
-// own one -- out = {panels, rows, rows padded to 16-row tiles, member entries, slots, cap, rows_cap, n_mat, fixups}.
+// own one -- out = {panels, rows, rows padded to 16-row tiles, member entries, slots, cap, rows_cap, n_mat, hop-1 steps}.
 __attribute__((visibility("default"))) int hg_debug_fused_shape(const hg_plan *p, int32_t F, int32_t lin, int64_t *out9) {
   const hg::FusedSched *f = nullptr;
   int rc = get_fused(p, F, plan_vec4(p, F), &f, lin != 0);
@@ -894,7 +928,7 @@ __attribute__((visibility("default"))) int hg_debug_fused_shape(const hg_plan *p
     slots += pn.nslots;
   }
   const int64_t v[9] = {(int64_t)f->panels.size(), rows, padded, f->pmem_entries, slots, f->cap, f->rows_cap, f->n_mat,
-                        (int64_t)f->fixups.size()};
+                        f->stream_entries / std::max(1, f->ng)};  // [8]: hop-1 steps summed over the panels
   for (int i = 0; i < 9; i++) out9[i] = v[i];
   return HG_OK;
 }

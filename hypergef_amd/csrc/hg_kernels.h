@@ -136,6 +136,7 @@ hipError_t launch_wgrad(int64_t nrows, int32_t Fa, int32_t Fb, const float *A, c
 hipError_t launch_linear_pack(int32_t F_out, int32_t F_in, const float *Wlin, float *wfrag, hipStream_t stream);
 int fused_tile_row_floats(int F, bool vec4);
 hipError_t read_stamps(unsigned long long *out, bool reset);
+hipError_t launch_mfma_rate(int blocks, int iters, float *sink, unsigned long long *ticks, hipStream_t stream);
 hipError_t launch_push(const PushArgs &a, hipStream_t stream);
 hipError_t launch_bind_scales(int64_t nslots, const int32_t *eid_all, const float *degE, const float *W,
                               float *bsA, float *bsB, int64_t nrows, const int32_t *prow, const float *degV,

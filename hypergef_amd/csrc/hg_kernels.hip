@@ -654,22 +654,26 @@ __device__ __forceinline__ void panel_times_wt_staged_chunked(float *t, int nrow
 }
 
 // K = 128, staged-only instances (round 4).  The chunked phase above keeps ONE chunk of 8 k-steps in flight behind the
-// chunk that feeds the matrix pipe: 16 MFMAs = 512 cycles of cover for an L2 round trip of 1-2 thousand cycles under
-// load, eight times per panel and wave -- phase stamps put 41 % of a workgroup's life into this loop, four times the
-// matrix pipe's own time for it.  Here the wave holds a whole column tile of B (32 fragment registers, loaded before hop 2
-// and the barriers that precede the phase), and its second column tile streams into those registers chunk by chunk as
-// the first tile's k-steps retire: every load has a whole column tile's MFMAs (2048 cycles and more) to land.  The
-// registers come for free: at K = 128 the LDS tile holds occupancy to 5 workgroups per CU, i.e. 96 VGPRs per lane.
-template <int KSTEPS, int NPW, int NRT>
+// chunk that feeds the matrix pipe: 16 MFMAs = 512 cycles of cover for an L2 round trip of a thousand cycles and more
+// under load, eight times per panel and wave.  Here the wave's B fragments travel through a ring of D chunk buffers
+// (8 registers each): chunks 0 .. D-1 of the first column tile are loaded ahead of the phase (before the barriers that
+// precede it), and as soon as a chunk's MFMAs have issued, the chunk D places further on -- this column tile's or the
+// next one's -- is loaded into its registers: every load has D - 1 chunks' MFMAs to land.  D = 3 fits the budget of
+// six waves per SIMD, which is what the LDS tile of the epilogue's schedule allows (a whole column tile, D = 4, needs
+// 96 registers: five waves, one workgroup per CU fewer, 10 % slower on the same box -- profiles/r04_experiments.md).
+#ifndef HG_LIN_RING
+#define HG_LIN_RING 0  // 0: off (the chunked phase above).  Measured on one box against it, pubmed x64 128 -> 128: D = 4 at
+#endif                 // five waves per SIMD +10 %, D = 3 and D = 2 at six +4..5 % (profiles/r04_experiments.md): not shipped.
+constexpr int ring_rpn(int npw) { return 4 / npw > 2 ? 2 : 4 / npw; }  // row tiles per column tile and wave: K = 128 panels have two at most
+template <int KSTEPS, int NPW, int NRT, int D>
 __device__ __forceinline__ void mfma_rows_ring(const float *ta, int tstep, const float *Wlin, const LinSplit &sp, int NT,
-                                               int lane, float (&b)[KSTEPS], hg_f4 *acc) {
-  constexpr int RPN = 4 / NPW, CH = 8, NCH = KSTEPS / CH;
+                                               int lane, float (&b)[D * 8], hg_f4 *acc) {
+  constexpr int RPN = ring_rpn(NPW), CH = 8, NCH = KSTEPS / CH;
+  static_assert(D >= 1 && D <= NCH, "ring of up to NCH chunks");
 #pragma unroll
   for (int ni = 0; ni < NPW; ni++) {
     const int nt = sp.nt_first + ni * sp.nt_step;
     if (nt < NT) {  // wave-uniform
-      const int nt2 = sp.nt_first + (ni + 1) * sp.nt_step;
-      const bool more = ni + 1 < NPW && nt2 < NT;
       float a0[NRT], a1[NRT], a2[NRT];
 #pragma unroll
       for (int j = 0; j < NRT; j++) {
@@ -678,6 +682,7 @@ __device__ __forceinline__ void mfma_rows_ring(const float *ta, int tstep, const
       }
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
+        const int q = ni * NCH + c, slot = q % D;  // constants after unrolling
 #pragma unroll
         for (int k8 = 0; k8 < CH; k8++) {
           const int ks = c * CH + k8;
@@ -688,7 +693,7 @@ __device__ __forceinline__ void mfma_rows_ring(const float *ta, int tstep, const
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int j = 0; j < NRT; j++)
-            acc[ni * RPN + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b[ks], acc[ni * RPN + j], 0, 0, 0);
+            acc[ni * RPN + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b[slot * CH + k8], acc[ni * RPN + j], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int j = 0; j < NRT; j++) {
@@ -696,11 +701,14 @@ __device__ __forceinline__ void mfma_rows_ring(const float *ta, int tstep, const
             a1[j] = a2[j];
           }
         }
-        if (more) {  // this chunk's registers are free: the next column tile's chunk c lands in them
-          const float4 *w = reinterpret_cast<const float4 *>(Wlin) + ((int64_t)nt2 * (KSTEPS / 4) + 2 * c) * 64 + lane;
+        // this chunk's registers are free: chunk q + D lands in them
+        const int q2 = q + D, ni2 = q2 / NCH, c2 = q2 % NCH;
+        const int nt2 = sp.nt_first + ni2 * sp.nt_step;
+        if (ni2 < NPW && nt2 < NT) {  // wave-uniform
+          const float4 *w = reinterpret_cast<const float4 *>(Wlin) + ((int64_t)nt2 * (KSTEPS / 4) + 2 * c2) * 64 + lane;
           const float4 f0 = w[0], f1 = w[64];
-          b[c * CH + 0] = f0.x; b[c * CH + 1] = f0.y; b[c * CH + 2] = f0.z; b[c * CH + 3] = f0.w;
-          b[c * CH + 4] = f1.x; b[c * CH + 5] = f1.y; b[c * CH + 6] = f1.z; b[c * CH + 7] = f1.w;
+          b[slot * CH + 0] = f0.x; b[slot * CH + 1] = f0.y; b[slot * CH + 2] = f0.z; b[slot * CH + 3] = f0.w;
+          b[slot * CH + 4] = f1.x; b[slot * CH + 5] = f1.y; b[slot * CH + 6] = f1.z; b[slot * CH + 7] = f1.w;
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -708,28 +716,42 @@ __device__ __forceinline__ void mfma_rows_ring(const float *ta, int tstep, const
   }
 }
 
-// The staged form (see panel_times_wt_staged) on the ring matrix phase.  b: the wave's whole first column tile.
-template <int KSTEPS, int NPW>
+// chunks 0 .. D-1 of column tile nt: what mfma_rows_ring expects in its ring when it starts
+template <int KSTEPS, int D>
+__device__ __forceinline__ void load_bfrag_ring(const float *wfrag, int nt, int lane, float (&b)[D * 8]) {
+  const float4 *w = reinterpret_cast<const float4 *>(wfrag) + (int64_t)nt * (KSTEPS / 4) * 64 + lane;
+#pragma unroll
+  for (int q = 0; q < 2 * D; q++) {
+    const float4 f = w[q * 64];
+    b[q * 4 + 0] = f.x;
+    b[q * 4 + 1] = f.y;
+    b[q * 4 + 2] = f.z;
+    b[q * 4 + 3] = f.w;
+  }
+}
+
+// The staged form (see panel_times_wt_staged) on the ring matrix phase.  b: the ring, filled by load_bfrag_ring.
+template <int KSTEPS, int NPW, int D>
 __device__ __forceinline__ void panel_times_wt_staged_ring(float *t, int nrows, int F_out, const float *Wlin,
-                                                           const int32_t *rowmap, float *Y, int tid, float (&b)[KSTEPS],
+                                                           const int32_t *rowmap, float *Y, int tid, float (&b)[D * 8],
                                                            int relu, Stamper &stp) {
-  constexpr int K = KSTEPS * 4, LD = K + 4, RPN = 4 / NPW;
+  constexpr int K = KSTEPS * 4, LD = K + 4, RPN = ring_rpn(NPW);
   const int lane = tid & 63;
   const int NT = F_out >> 4, RT = (nrows + 15) >> 4;
   const LinSplit sp = lin_split(tid >> 6, NT);
-  hg_f4 acc[4];
+  hg_f4 acc[NPW * RPN];
 #pragma unroll
-  for (int j = 0; j < 4; j++) acc[j] = hg_f4{0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < NPW * RPN; j++) acc[j] = hg_f4{0.f, 0.f, 0.f, 0.f};
   int nrt = 0;
   if (sp.active) {
-    nrt = min(min(RPN, 2), max(0, (RT - sp.rt_first + sp.rt_step - 1) / sp.rt_step));
+    nrt = min(RPN, max(0, (RT - sp.rt_first + sp.rt_step - 1) / sp.rt_step));
     const float *ta = t + (sp.rt_first * 16 + (lane & 15)) * LD + (lane >> 4);
     const int tstep = sp.rt_step * 16 * LD;
     // K = 128 panels hold at most 4 rows per lane group x 8 lane groups = two row tiles (launcher): nrt <= 2.  The three-
     // and four-tile forms are not compiled in -- their A-fragment registers were what spilled at this budget.
     switch (nrt) {  // wave-uniform
-      case 2: if constexpr (RPN >= 2) mfma_rows_ring<KSTEPS, NPW, 2>(ta, tstep, Wlin, sp, NT, lane, b, acc); break;
-      case 1: mfma_rows_ring<KSTEPS, NPW, 1>(ta, tstep, Wlin, sp, NT, lane, b, acc); break;
+      case 2: if constexpr (RPN >= 2) mfma_rows_ring<KSTEPS, NPW, 2, D>(ta, tstep, Wlin, sp, NT, lane, b, acc); break;
+      case 1: mfma_rows_ring<KSTEPS, NPW, 1, D>(ta, tstep, Wlin, sp, NT, lane, b, acc); break;
       default: break;
     }
   }
@@ -1005,13 +1027,21 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *partial,
 #ifndef HG_LIN_WAVES_STAGED
 #define HG_LIN_WAVES_STAGED 8
 #endif
-// K = 128 staged-only instances: the LDS tile of the epilogue's schedule (48 slots x 132 floats + record) allows five
-// workgroups per CU anyway; the register budget that goes with five waves per SIMD holds a whole B column tile
+// K = 128 staged-only instances: the register budget of six waves per SIMD, which is what the LDS tile of the epilogue's
+// schedule allows anyway (48 slots x 132 floats + record = 26.6 KB: six workgroups per CU); it pays for twelve row
+// gathers in flight per lane (HG_LIN_U32) -- most panels' hop 1 is then one round trip (HG_LIN_MERGE_PHASES)
 #ifndef HG_LIN_WAVES_STAGED32
-#define HG_LIN_WAVES_STAGED32 5
+#define HG_LIN_WAVES_STAGED32 6
+#endif
+#ifndef HG_LIN_MERGE_PHASES
+#define HG_LIN_MERGE_PHASES 1  // K = 128 staged epilogue instances: hop 1's two phases as one run of batches (with twelve gathers in
+                               // flight at the six-wave budget: -1.2 % on pubmed x64 128 -> 128, -2.2 % on 128 -> 64, same box, three rounds)
+#endif
+#ifndef HG_LIN_HOP2_BATCH
+#define HG_LIN_HOP2_BATCH 0
 #endif
 #ifndef HG_LIN_U32
-#define HG_LIN_U32 12  // row gathers in flight per lane, K = 128 staged instances: two batches cover the 24 steps of a 48-slot panel (16 spills at 96 VGPRs)
+#define HG_LIN_U32 12  // row gathers in flight per lane, K = 128 staged instances
 #endif
 typedef unsigned hg_u4 __attribute__((ext_vector_type(4)));
 typedef int hg_i4 __attribute__((ext_vector_type(4)));
@@ -1168,12 +1198,52 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
       }
     };
     const int steps_x = MAT ? rec[8] : steps;
-    int s0 = 0;
-    for (; s0 + U <= steps_x; s0 += U) block(s0, steps_x, std::true_type{}, std::false_type{});
-    if (s0 < steps_x) block(s0, steps_x, std::false_type{}, std::false_type{});
-    if constexpr (MAT) {
-      for (s0 = steps_x; s0 + U <= steps; s0 += U) block(s0, steps, std::true_type{}, std::true_type{});
-      if (s0 < steps) block(s0, steps, std::false_type{}, std::true_type{});
+    if constexpr (MAT && FAST && HG_LIN_MERGE_PHASES && LIN && !LINW && LPR >= 32) {
+      // Both phases in ONE run of batches, the descriptor picked per step (wave-uniform): a pubmed-shape panel of the
+      // epilogue's schedule has ~7 steps of X rows and ~4 of materialised rows -- two dependent round trips as two
+      // phases, one as a batch of twelve.
+      auto mixed = [&](const int s0, auto full) {
+        constexpr bool FULL = decltype(full)::value;
+        int ent[U];
+#pragma unroll
+        for (int j = 0; j < U; j++) ent[j] = (FULL || s0 + j < steps) ? stream[(s0 + j) * NG + g] : 0;
+        V v[U];
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+          if (!FULL && s0 + j >= steps) {  // wave-uniform: no load is issued for a step that is not there
+            v[j] = V::zero();
+            continue;
+          }
+          const unsigned off = __umul24((unsigned)ent[j], row_bytes) + col_off;  // flags sit above bit 23
+          if (s0 + j >= steps_x) v[j] = V::load_buf(rm, off);  // wave-uniform
+          else v[j] = V::load_buf(rx, off);
+        }
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+          acc.add(v[j]);
+          if (ent[j] < 0) {
+            if constexpr (SCALED) {
+              if (a.degE) acc.mul(sA[slot]);
+              if (a.W) acc.mul(sB[slot]);
+              slot++;
+            }
+            acc.store(tp);
+            tp += TW;
+            acc = V::zero();
+          }
+        }
+      };
+      int s0 = 0;
+      for (; s0 + U <= steps; s0 += U) mixed(s0, std::true_type{});
+      if (s0 < steps) mixed(s0, std::false_type{});
+    } else {
+      int s0 = 0;
+      for (; s0 + U <= steps_x; s0 += U) block(s0, steps_x, std::true_type{}, std::false_type{});
+      if (s0 < steps_x) block(s0, steps_x, std::false_type{}, std::false_type{});
+      if constexpr (MAT) {
+        for (s0 = steps_x; s0 + U <= steps; s0 += U) block(s0, steps, std::true_type{}, std::true_type{});
+        if (s0 < steps) block(s0, steps, std::false_type{}, std::true_type{});
+      }
     }
   }
   HG_STAMP(3);
@@ -1183,31 +1253,42 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
     // The B fragments of this wave's first column tile are issued after hop 2 and fly across the two barriers that follow
     // (before hop 2 they would sit in registers through it: spills).  RING (K = 128, staged only): the whole column tile
     // (mfma_rows_ring); the others: what BPre says.
-    constexpr bool RING = !LINW && TW / 4 >= 32;
-    float bv[RING ? TW / 4 : BPre<TW / 4>::N];
+    constexpr bool RING = HG_LIN_RING > 0 && !LINW && TW / 4 >= 32;
+    constexpr int RD = HG_LIN_RING > 0 ? HG_LIN_RING : 1;
+    float bv[RING ? RD * 8 : BPre<TW / 4>::N];
     const LinSplit sp = lin_split(tid >> 6, a.F_out >> 4);
     const int rpg = (nrows + NG - 1) / NG;  // <= 4 (launcher)
     const int r0 = min(g * rpg, nrows), r1 = min(r0 + rpg, nrows);
     V outr[4];
+#if HG_LIN_HOP2_BATCH
     // The lane group's (up to) four rows are walked together: their list ends in one LDS round trip, then per step the
     // four slot ids and the four tile rows in flight at once -- row after row the same reads are a chain of some twenty
     // dependent LDS latencies, 18 % of a workgroup's life at F = 128 (phase stamps).  Each row still adds its slots in
     // list order: same bits.  The trip count is the wave's longest list (wave-uniform); a step past a row's end re-reads
     // slot 0 and is not added.
+    // Every LDS read below is unconditional, at a clamped position, and masked afterwards: a conditional read becomes a
+    // branch with its own s_waitcnt, which is the serial chain again.
     int pb_[4], n_[4], len = 0;
+    {
+      const int rl = max(nrows - 1, 0);
+      int e_[5];  // list ends of rows r0 - 1 .. r0 + 3 (clamped)
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      outr[i] = V::zero();
-      const int r = r0 + i;
-      const bool ok = r < r1;
-      pb_[i] = (ok && r) ? (int)pend[r - 1] : 0;
-      n_[i] = ok ? (int)pend[r] - pb_[i] : 0;
-      len = max(len, n_[i]);
+      for (int i = 0; i < 5; i++) e_[i] = (int)pend[min(max(r0 + i - 1, 0), rl)];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        outr[i] = V::zero();
+        const int r = r0 + i;
+        const int okm = -(int)(r < r1);                 // all ones / zero
+        pb_[i] = e_[i] & okm & -(int)(r > 0);
+        n_[i] = (e_[i + 1] & okm) - pb_[i];
+        len = max(len, n_[i]);
+      }
     }
+    const int last = max((int)pend[max(nrows - 1, 0)] - 1, 0);  // last valid position of the slot-id list
     for (int k = 0; __builtin_amdgcn_ballot_w64(k < len) != 0; k++) {
       int sidx[4];
 #pragma unroll
-      for (int i = 0; i < 4; i++) sidx[i] = k < n_[i] ? (int)pvs[pb_[i] + k] : 0;
+      for (int i = 0; i < 4; i++) sidx[i] = (int)pvs[min(pb_[i] + k, last)] & -(int)(k < n_[i]);
       V t[4];
 #pragma unroll
       for (int i = 0; i < 4; i++) t[i] = V::load(tile + sidx[i] * TW + lcol);
@@ -1220,6 +1301,21 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
       for (int i = 0; i < 4; i++)
         if (n_[i] > 0) outr[i].mul(sdeg[r0 + i]);
     }
+#else
+    // row after row.  (HG_LIN_HOP2_BATCH = 1 walks the lane group's four rows together -- list ends in one LDS round trip,
+    // four slot ids and four tile rows in flight per step, every read unconditional and masked: measured 4-5 % SLOWER on
+    // the pubmed x64 128 -> 128 batch with the B ring, same box; profiles/r04_experiments.md.)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      outr[i] = V::zero();
+      const int r = r0 + i;
+      if (r < r1) {
+        const int pb = r ? pend[r - 1] : 0, pe = pend[r];
+        for (int p = pb; p < pe; p++) outr[i].add(V::load(tile + (int)pvs[p] * TW + lcol));
+        if (a.degV && pe > pb) outr[i].mul(sdeg[r]);
+      }
+    }
+#endif
     if (a.epi.R || a.epi.ca != 1.f) {  // t' = ca * t + cb * R[v]  (workgroup-uniform)
       const float cb = a.epi.cb_dev ? *a.epi.cb_dev : a.epi.cb;
 #pragma unroll
@@ -1234,7 +1330,7 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
         }
     }
     if (sp.active && !(DBG && (a.debug & 512))) {
-      if constexpr (RING) load_bfrag<TW / 4>(a.Wlin, sp.nt_first, tid & 63, bv);
+      if constexpr (RING) load_bfrag_ring<TW / 4, RD>(a.Wlin, sp.nt_first, tid & 63, bv);
       else load_bfrag_pre<TW / 4>(a.Wlin, sp.nt_first, tid & 63, bv);
     }
     HG_STAMP(5);
@@ -1263,8 +1359,8 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
     }
     HG_STAMP(7);
     if constexpr (RING) {
-      if (a.F_out > 64) panel_times_wt_staged_ring<TW / 4, 2>(tile, nrows, a.F_out, a.Wlin, prow, a.Y, tid, bv, a.epi.relu, stp);
-      else panel_times_wt_staged_ring<TW / 4, 1>(tile, nrows, a.F_out, a.Wlin, prow, a.Y, tid, bv, a.epi.relu, stp);
+      if (a.F_out > 64) panel_times_wt_staged_ring<TW / 4, 2, RD>(tile, nrows, a.F_out, a.Wlin, prow, a.Y, tid, bv, a.epi.relu, stp);
+      else panel_times_wt_staged_ring<TW / 4, 1, RD>(tile, nrows, a.F_out, a.Wlin, prow, a.Y, tid, bv, a.epi.relu, stp);
     } else {
       panel_times_wt<TW / 4, LINW>(tile, nrows, a.F_out, a.Wlin, prow, 0, a.Y, tid, bv, a.epi.relu, stp);
     }
@@ -2064,6 +2160,34 @@ hipError_t launch_fused(const FusedArgs &a, bool vec4, hipStream_t stream) {
   }
 #undef HG_CASE
   return hipErrorInvalidValue;
+}
+
+// Diagnostic: what the matrix pipes sustain on v_mfma_f32_16x16x4_f32 with operands in registers -- eight waves per
+// SIMD, four independent accumulators each, `iters` rounds of 16 MFMAs -- and the shader clock meanwhile (s_memtime
+// ticks per wave).  The roofline's 157 TFLOP/s is 64 FLOP / clk / SIMD at 2.4 GHz.
+__global__ __launch_bounds__(256) void mfma_rate_kernel(int iters, float *sink, unsigned long long *ticks) {
+  hg_f4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) acc[j] = hg_f4{0.f, 0.f, 0.f, 0.f};
+  float a = (float)threadIdx.x * 1e-3f, b = (float)blockIdx.x * 1e-6f + 1.f;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < iters; i++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[j], 0, 0, 0);
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; j++) s += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+  if (s == 12345.678f) sink[0] = s;  // keeps the accumulators alive
+  if (threadIdx.x == 0 && blockIdx.x == 0) ticks[0] = t1 - t0;
+}
+
+hipError_t launch_mfma_rate(int blocks, int iters, float *sink, unsigned long long *ticks, hipStream_t stream) {
+  hipLaunchKernelGGL(mfma_rate_kernel, dim3(blocks), dim3(256), 0, stream, iters, sink, ticks);
+  return hipGetLastError();
 }
 
 hipError_t read_stamps(unsigned long long *out, bool reset) {
