@@ -928,7 +928,7 @@ __attribute__((visibility("default"))) int hg_debug_fused_shape(const hg_plan *p
     slots += pn.nslots;
   }
   const int64_t v[9] = {(int64_t)f->panels.size(), rows, padded, f->pmem_entries, slots, f->cap, f->rows_cap, f->n_mat,
-                        f->stream_entries / std::max(1, f->ng)};  // [8]: hop-1 steps summed over the panels
+                        f->stream_entries / std::max(1, f->ng) * 100000 + f->max_rec_words};  // [8]: hop-1 steps summed over the panels * 1e5 + record words
   for (int i = 0; i < 9; i++) out9[i] = v[i];
   return HG_OK;
 }

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 
 #include <type_traits>
@@ -322,9 +323,12 @@ struct Stamper {
   bool on = false;
   unsigned long long st[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t0 = 0;
+  unsigned long long c0 = 0, r0 = 0;  // shader-clock and 100 MHz wall-clock readings at init: their deltas (counters 13, 14) give the clock
   __device__ __forceinline__ void init(bool cond) {
     on = cond;
     t0 = on ? __builtin_amdgcn_s_memtime() : 0;
+    c0 = t0;
+    r0 = on ? __builtin_amdgcn_s_memrealtime() : 0;
   }
   __device__ __forceinline__ void mark(int i) {
     if (on) {
@@ -334,6 +338,10 @@ struct Stamper {
     }
   }
   __device__ __forceinline__ void flush() {
+    if (on) {
+      st[13] = __builtin_amdgcn_s_memtime() - c0;
+      st[14] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
     if (on && (threadIdx.x & 63) == 0)
       for (int i = 0; i < 16; i++)
         if (st[i]) atomicAdd(&hg_stamps[i], st[i]);
@@ -351,7 +359,17 @@ struct Stamper {
 #define HG_STAMP_INIT(cond) [[maybe_unused]] Stamper stp
 #endif
 #define HG_STAMP(i) stp.mark(i)
+#ifdef HG_STAMPS
+// stamp 12: how long the wave's own stores take to be acknowledged after their issue (the wave cannot retire before)
+#define HG_STAMP_FLUSH()                                  \
+  do {                                                    \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      \
+    stp.mark(12);                                         \
+    stp.flush();                                          \
+  } while (0)
+#else
 #define HG_STAMP_FLUSH() stp.flush()
+#endif
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the
 // vector-memory counter, which on CDNA4 counts stores: in a persistent loop that would
@@ -1033,6 +1051,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *partial,
 #ifndef HG_LIN_WAVES_STAGED32
 #define HG_LIN_WAVES_STAGED32 6
 #endif
+#ifndef HG_LIN_PERSIST
+#define HG_LIN_PERSIST 0  // 1: linear-epilogue instances as one resident round of workgroups walking their panels (fused_packed_kernel).
+                          // Measured, same box: pubmed x64 128 -> 128 0.644 -> 0.672 ms, cora x1024 64 -> 64 0.475 -> 0.570; fewer panels
+                          // per workgroup (12 / 24 rounds of workgroups) converge back to the one-panel figure; staggered starts: no
+                          // change (profiles/r04_experiments.md).  Off.
+#endif
 #ifndef HG_LIN_MERGE_PHASES
 #define HG_LIN_MERGE_PHASES 1  // K = 128 staged epilogue instances: hop 1's two phases as one run of batches (with twelve gathers in
                                // flight at the six-wave budget: -1.2 % on pubmed x64 128 -> 128, -2.2 % on 128 -> 64, same box, three rounds)
@@ -1071,27 +1095,30 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
   constexpr int TW = LPR * VEC;
   using V = Vec<VEC>;
   extern __shared__ int32_t smem[];
-  const int tid = threadIdx.x;
-  const int gl = tid & (LPR - 1);
-  const int lcol = gl * VEC;
-  const int col = blockIdx.y * TW + lcol;
-  const bool col_ok = col < a.F;
   const int64_t F = a.F;
-  int b = blockIdx.x;
-  if (a.xcd_remap) {
-    const int x = b & 7;
-    int i = b >> 3;
-    const int cpx = a.npanels >> 3, rem = a.npanels & 7;
-    // After a substantial materialisation pre-pass each XCD walks its run of panels backwards: the pre-pass walked the
-    // hyperedges forwards, so the member rows it read last -- still in the L2 / Infinity Cache -- are the ones the
-    // panels ask for first (pubmed-shape batches at F = 64 .. 128: -2 .. -3.6 % per step; neutral elsewhere).
-    if (MAT && a.reverse_runs) i = cpx + (x < rem ? 1 : 0) - 1 - i;
-    b = x * cpx + (x < rem ? x : rem) + i;
-  }
+  // PERSIST (linear-epilogue instances, HG_LIN_PERSIST = 1: experiment, off): the grid is one resident round of workgroups
+  // and each walks its share of the panels in a loop.  Phase stamps count about 4.2 workgroups' worth of in-code time in
+  // flight per CU where six are resident: the rest of a slot's time passes between one workgroup's end and the next
+  // one's first instruction.  Closing that gap this way did not pay (see HG_LIN_PERSIST), as for the plain panels in round 2.
+  constexpr bool PERSIST = LIN && (HG_LIN_PERSIST != 0);
+  const int cpx = a.npanels >> 3, rem = a.npanels & 7;
+  // workgroups are dealt round-robin to the 8 XCDs; each XCD owns one contiguous run of panels (neighbouring panels share
+  // an L2).  After a substantial materialisation pre-pass the run is walked backwards: the pre-pass walked the hyperedges
+  // forwards, so the member rows it read last -- still in the L2 / Infinity Cache -- are the ones the panels ask for
+  // first (pubmed-shape batches at F = 64 .. 128: -2 .. -3.6 % per step; neutral elsewhere).
+  const int xcd = a.xcd_remap ? (int)(blockIdx.x & 7) : 0;
+  const int run_len = a.xcd_remap ? cpx + (xcd < rem ? 1 : 0) : a.npanels;
+  const int run0 = a.xcd_remap ? xcd * cpx + (xcd < rem ? xcd : rem) : 0;
+  const int i_first = a.xcd_remap ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int i_step = PERSIST ? (a.xcd_remap ? (int)(gridDim.x >> 3) : (int)gridDim.x) : run_len;  // not PERSIST: one panel
   HG_STAMP_INIT(true);
-  const FRec rt = a.rec_tab[b];
-  HG_STAMP(0);
-  const int32_t *grec = a.rec + rt.off;
+  if constexpr (PERSIST) {
+    // The resident round starts all at once and every panel takes about as long as the next: left alone the workgroups of
+    // a CU stay in step -- all in hop 1 together, all at the matrix pipe together.  Each CU slot starts a little later
+    // than the one before (the dispatcher deals a round of 32 workgroups per XCD across its 32 CUs).
+    const int slot = (int)((blockIdx.x >> 3) >> 5) & 7;
+    for (int k = 0; k < slot * a.stagger; k++) __builtin_amdgcn_s_sleep(16);  // 1024 cycles each; a fixed, finite count
+  }
 
   float *tile = reinterpret_cast<float *>(smem);        // [cap * TW]  (LIN: [cap * (TW + 4)])
   int32_t *rec = smem + a.cap * (LIN ? TW + 4 : TW);     // [max_rec_words], 16-byte aligned
@@ -1099,6 +1126,21 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
   float *sA = reinterpret_cast<float *>(rec + a.max_rec_words);  // [cap]
   float *sB = sA + a.cap;                                // [cap]
   float *sdeg = (a.degE || a.W) ? sB + a.cap : sA;       // [rows_cap]
+
+  auto run_panel = [&](const int b) {
+  // PERSIST: everything derived from the thread index is recomputed per panel from an opaque copy -- left alone the
+  // compiler hoists all of it (lane addresses of the tile, the operand rows, the B fragments ...) out of the panel loop
+  // and keeps it live across the whole body: 100-230 bytes of scratch per lane.
+  int tid_ = threadIdx.x;
+  if constexpr (PERSIST) asm volatile("" : "+v"(tid_));
+  const int tid = tid_;
+  const int gl = tid & (LPR - 1);
+  const int lcol = gl * VEC;
+  const int col = blockIdx.y * TW + lcol;
+  const bool col_ok = col < a.F;
+  const FRec rt = a.rec_tab[b];
+  HG_STAMP(0);
+  const int32_t *grec = a.rec + rt.off;
 
   // records are padded to whole 16-byte units: one dwordx4 per lane copies 4 KB per pass
   for (int i = tid; i < (rt.len >> 2); i += BS)
@@ -1364,7 +1406,6 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
     } else {
       panel_times_wt<TW / 4, LINW>(tile, nrows, a.F_out, a.Wlin, prow, 0, a.Y, tid, bv, a.epi.relu, stp);
     }
-    HG_STAMP_FLUSH();
     return;
   } else if (!(DBG && (a.debug & 8))) {  // ---- hop 2
     const int rpg = (nrows + NG - 1) / NG;
@@ -1384,6 +1425,14 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
     }
   }
   HG_STAMP(5);
+  };  // run_panel
+
+  for (int i = i_first; i < run_len; i += i_step) {
+    const int ii = (MAT && a.reverse_runs && a.xcd_remap) ? run_len - 1 - i : i;
+    run_panel(run0 + ii);
+    if constexpr (!PERSIST) break;
+    lds_barrier();  // every wave is done with the tile and the record (its last LDS reads fed the row stores): next panel
+  }
   HG_STAMP_FLUSH();
 }
 
@@ -1794,8 +1843,47 @@ static hipError_t launch_lds(dim3 grid, size_t lds, hipStream_t stream, const Ar
     if (e != hipSuccess) return e;
     granted.store(kLdsMax, std::memory_order_relaxed);
   }
+#ifdef HG_TUNING
+  // diagnostic build, HG_PRINT_OCC=1: what the runtime says about resident workgroups per CU for this launch
+  static const bool print_occ = [] { const char *e = getenv("HG_PRINT_OCC"); return e && atoi(e) != 0; }();
+  if (print_occ) {
+    static std::atomic<size_t> last{(size_t)-1};
+    if (last.exchange(lds) != lds) {
+      int n = -1;
+      hipFuncAttributes fa{};
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(Kern), BLOCK, lds);
+      (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(Kern));
+      fprintf(stderr, "[hg occ] %s: block %d, dynamic LDS %zu B, static LDS %zu B, %d VGPRs -> %d workgroups per CU, grid %u x %u\n",
+              __PRETTY_FUNCTION__, BLOCK, lds, (size_t)fa.sharedSizeBytes, fa.numRegs, n, grid.x, grid.y);
+    }
+  }
+#endif
   hipLaunchKernelGGL(Kern, grid, dim3(BLOCK), lds, stream, a);
   return hipGetLastError();
+}
+
+// One resident round of workgroups for a persistent kernel: (what the runtime says fits a CU) x CUs, a multiple of 8 (one
+// share per XCD), at least 8 and no more than `work` rounded up to 8.  Asked once per kernel instance and LDS size.
+template <auto Kern, int BLOCK = 256>
+static unsigned resident_grid(size_t lds, int work) {
+  static std::atomic<size_t> known_lds{(size_t)-1};
+  static std::atomic<int> known{0};
+  int per_cu = known.load(std::memory_order_relaxed);
+  if (known_lds.load(std::memory_order_relaxed) != lds || per_cu <= 0) {
+    int n = 0, cus = 0, dev = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(Kern), BLOCK, lds) != hipSuccess || n <= 0) n = 1;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    per_cu = n * cus;
+    known.store(per_cu, std::memory_order_relaxed);
+    known_lds.store(lds, std::memory_order_relaxed);
+  }
+#ifdef HG_TUNING
+  static const int force = [] { const char *e = getenv("HG_LIN_PERSIST_PER_CU"); return e ? atoi(e) : 0; }();
+  if (force > 0) per_cu = force * 256;  // diagnostic build: workgroups per CU of the resident round
+#endif
+  const int want = std::min(per_cu, (work + 7) / 8 * 8);
+  return (unsigned)std::max(8, want / 8 * 8);
 }
 
 template <int LPR, int VEC>
@@ -1994,6 +2082,10 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
   const Tuning &t = tuning();
   FusedArgs ad = a;
   ad.debug = t.fused_debug;
+#ifdef HG_TUNING
+  static const int stagger = [] { const char *e = getenv("HG_LIN_STAGGER"); return e ? atoi(e) : 0; }();
+  ad.stagger = std::max(0, std::min(stagger, 64));
+#endif
   const dim3 grid(a.npanels, col_tiles);
   // tile | record | scale staging (only what this call's scales need: without them the F = 32
   // bench shape fits 8 workgroups per CU instead of 7)
@@ -2013,12 +2105,17 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
         // K = 128, staged: the LDS tile already holds occupancy to five workgroups per CU, so the registers for twelve row
         // gathers in flight per lane cost nothing there (a panel's hop 1 is then two dependent batches instead of three)
         constexpr int UL = LPR >= 32 ? HG_LIN_U32 : 8;
+        // HG_LIN_PERSIST: one resident round of workgroups, each walking its share of the panels (fused_packed_kernel)
+#define HG_PKG(KERN) (HG_LIN_PERSIST ? dim3(resident_grid<KERN>(lds_l, a.npanels), col_tiles) : grid)
 #define HG_PKL(M, S)                                                                                                          \
-  return staged ? launch_lds<fused_packed_kernel<LPR, VEC, UL, true, M, S, false, true, 256, false>>(grid, lds_l, stream, ad) \
-                : launch_lds<fused_packed_kernel<LPR, VEC, 8, true, M, S, false, true, 256, true>>(grid, lds_l, stream, ad)
+  return staged ? launch_lds<fused_packed_kernel<LPR, VEC, UL, true, M, S, false, true, 256, false>>(                         \
+                      HG_PKG((fused_packed_kernel<LPR, VEC, UL, true, M, S, false, true, 256, false>)), lds_l, stream, ad)    \
+                : launch_lds<fused_packed_kernel<LPR, VEC, 8, true, M, S, false, true, 256, true>>(                           \
+                      HG_PKG((fused_packed_kernel<LPR, VEC, 8, true, M, S, false, true, 256, true>)), lds_l, stream, ad)
 #ifdef HG_TUNING
         if (t.fused_debug & (768 | 1 | 32))  // ablations of the matrix phase / the gathers (tools/linear_probe.py): diagnostic build only
-          return launch_lds<fused_packed_kernel<LPR, VEC, 8, true, true, true, true, true>>(grid, lds_l, stream, ad);
+          return launch_lds<fused_packed_kernel<LPR, VEC, 8, true, true, true, true, true>>(
+              HG_PKG((fused_packed_kernel<LPR, VEC, 8, true, true, true, true, true>)), lds_l, stream, ad);
 #endif
         switch (spec) {
           case 0: HG_PKL(false, false);
@@ -2027,6 +2124,7 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
           default: HG_PKL(true, true);
         }
 #undef HG_PKL
+#undef HG_PKG
       } else {
         return hipErrorInvalidValue;
       }
