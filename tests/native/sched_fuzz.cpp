@@ -23,7 +23,7 @@
 // (entry streams, tiles, 16-bit pair lists, register rows, partial rows per workgroup), panel records
 // (piece rows with bit 31), fixups (first level, then final) -- on exact integer "features", and
 // compare with Y = H H^T X computed directly.  Every vertex row must be written exactly once.
-static long g_stream_rows = 0, g_stream_chunks = 0, g_chunked = 0, g_hub_graphs = 0, g_hub_rounds = 0, g_hub_parts = 0, g_split_rows = 0, g_l1_fixups = 0, g_heavy = 0;
+static long g_stream_rows = 0, g_stream_chunks = 0, g_chunked = 0, g_hub_graphs = 0, g_hub_rounds = 0, g_hub_parts = 0, g_split_rows = 0, g_l1_fixups = 0, g_heavy = 0, g_rows_capped = 0;
 
 static void emulate_fused(const hg::FusedSched &f, int N, int M, const std::vector<int32_t> &ptr,
                           const std::vector<int32_t> &ind, const std::vector<int32_t> &ptr_v,
@@ -332,7 +332,15 @@ static void one_graph(std::mt19937 &rng, int N, int M, double mean, int hub_ever
         // 8 lanes x 4 floats per row, as F = 32; or (small hub tiles) 32 lanes x 4 floats, as F = 128
         // ... or (sub-slot schedules, 128-slot tiles) the 128 lane groups of a 1024-thread panel for tiny dense graphs
         const int ng = (hubs == 2 && cap == 128) ? 128 : (hubs && cap != 64) ? 8 : 32, row_floats = (hubs && cap != 64 && ng != 128) ? 128 : 32;
-        hg::build_fused(N, M, ptr.data(), ind.data(), ptr_v.data(), ind_v.data(), oh, cap, cap * 4, ng, row_floats, true, f);
+        // every third graph: the linear epilogue's panel shape -- fewer rows than slots (rows capped at 2/3 of the slots,
+        // whole 16-row tiles where the cap allows)
+        const int rows_cap = (N % 3 == 0 && hubs != 2) ? std::max(1, cap * 2 / 3 / 16 * 16) : 0;
+        hg::build_fused(N, M, ptr.data(), ind.data(), ptr_v.data(), ind_v.data(), oh, cap, cap * 4, ng, row_floats, true, f, rows_cap);
+        if (rows_cap) {
+          CHECK(f.rows_cap == std::min(rows_cap, cap));
+          for (const auto &pn : f.panels) CHECK(pn.nrows <= f.rows_cap);
+          g_rows_capped++;
+        }
         if (hubs == 2) {
           if (f.invalid) continue;  // a vertex's sub-slots exceed a panel: the plan discards such a schedule
           CHECK(f.n_mat == 0 && f.n_split == 0 && f.fixups.empty());
@@ -406,6 +414,7 @@ int main(int argc, char **argv) {
   // the random graphs must actually have reached the hub pass, hub parts, split rows and two-level fixups
   std::printf("hub schedules %ld, hub rounds %ld, heavy hubs %ld, extra hub parts %ld, split vertices %ld, first-level fixups %ld\n",
               g_hub_graphs, g_hub_rounds, g_heavy, g_hub_parts, g_split_rows, g_l1_fixups);
+  CHECK(g_rows_capped > 50);
   CHECK(g_stream_rows > 10000 && g_stream_chunks > 100 && g_chunked > 200 && g_heavy > 50 && g_hub_graphs > 50 && g_hub_rounds > 10 * g_hub_graphs && g_hub_parts > 0 && g_split_rows > 100 && g_l1_fixups > 0);
   std::puts("sched_fuzz ok");
   return 0;
