@@ -1107,6 +1107,9 @@ static int aggr_impl(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
           hg::FusedSched *m = const_cast<hg::FusedSched *>(fl);
           std::lock_guard<std::mutex> lock(const_cast<hg_plan *>(plan)->fused_mu);
           if ((rc = gather_bound_scales(m, degE, degV, W, s)) != HG_OK) return rc;
+          // first use only (it also allocated): wait for the gather, so that a later call on ANY stream finds the arrays
+          // complete -- the caller's binding event (plan.py) covers the default schedule's gather, not this one
+          (void)hipStreamSynchronize(s);
           m->bound_degE = degE;
           m->bound_W = W;
           m->bound_degV = degV;

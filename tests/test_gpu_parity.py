@@ -1139,6 +1139,47 @@ def test_training_step_replays_as_a_hipgraph(hg, model):
     planmod.clear_pack_cache()
 
 
+def test_linear_epilogue_own_schedule_on_a_batch(hg, oracle):
+    """Beyond 2^18 incidences a call with a linear at F = 128 runs the epilogue's own panel schedule (rows capped at four
+    per lane group, 48 slots: whole 16-row MFMA tiles; hg_api.hip, lin_caps) -- a batch of eight pubmed-shape hypergraphs
+    reaches it.  Weighted (scales bound to the default schedule first: the epilogue's schedule binds lazily) and
+    unweighted, against linear-then-aggregate through the oracle; deterministic; the plain aggregation of the same plan is
+    untouched by the second schedule."""
+    import ctypes
+    from hypergef_amd.plan import Plan
+    from hypergef_amd import _lib
+    inc = synth.replicate_block_diagonal(synth.pubmed_shape(), 8)
+    assert inc.nnz > 1 << 18
+    F = 128
+    X, degE, degV, W, H_ptr, H_ind = _inputs(inc, F, oracle, seed=41, normal=True)
+    rng = np.random.default_rng(42)
+    Wl = (rng.standard_normal((F, F)) / np.sqrt(F)).astype(np.float32)
+    ptr, ind = _dev(inc.csrptr), _dev(inc.colind)
+    plan = Plan.from_tensors(inc.N, ptr, ind)
+    y_plain = plan.aggregate(ptr, ind, _dev(X), _dev(degE.ravel()), _dev(degV.ravel()), _dev(W))  # binds the default schedule
+    ref_w = _linear_ref(oracle, inc, X, Wl, degE, degV, W, H_ptr, H_ind)
+    ref_u = _linear_ref(oracle, inc, X, Wl, None, None, None, H_ptr, H_ind)
+    for variant in ("auto", "fused"):
+        Yw = plan.aggregate_linear(ptr, ind, _dev(X), _dev(Wl), _dev(degE.ravel()), _dev(degV.ravel()), _dev(W), variant=variant)
+        _assert_close_linear(Yw, ref_w)
+        Yu = plan.aggregate_linear(ptr, ind, _dev(X), _dev(Wl), variant=variant)
+        _assert_close_linear(Yu, ref_u)
+        assert torch.equal(Yw, plan.aggregate_linear(ptr, ind, _dev(X), _dev(Wl), _dev(degE.ravel()), _dev(degV.ravel()), _dev(W),
+                                                     variant=variant))
+    # the schedule that ran: 32 rows of 48 slots per panel, fewer panels than the default one
+    L = _lib.lib()
+    L.hg_debug_fused_shape.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
+    own, dflt = (ctypes.c_int64 * 9)(), (ctypes.c_int64 * 9)()
+    assert L.hg_debug_fused_shape(plan._h, F, 1, own) == 0 and L.hg_debug_fused_shape(plan._h, F, 0, dflt) == 0
+    assert own[6] == 32 and own[5] == 48 and dflt[5] == 32 and own[0] < dflt[0]
+    assert own[2] / own[1] < dflt[2] / dflt[1]  # less padding to whole 16-row tiles
+    assert torch.equal(y_plain, plan.aggregate(ptr, ind, _dev(X), _dev(degE.ravel()), _dev(degV.ravel()), _dev(W)))
+    # F = 64 keeps the default schedule (its panels already hold 53 of 64 rows)
+    o64, d64 = (ctypes.c_int64 * 9)(), (ctypes.c_int64 * 9)()
+    assert L.hg_debug_fused_shape(plan._h, 64, 1, o64) == 0 and L.hg_debug_fused_shape(plan._h, 64, 0, d64) == 0
+    assert list(o64) == list(d64)
+
+
 def test_layer_scalar_from_device_memory(hg, oracle):
     """hg_aggr_linear_res_dev_f32: cb read from a device scalar gives the bits of hg_aggr_linear_res_f32 with the same
     value on the host, on the fused path and on the pull path (standalone rows kernel); a later write to the scalar is
