@@ -47,9 +47,6 @@ int resolve_opts(const hg_plan_opts *in, hg::Opts &o) {
     }
     if (in->fused_steps > 0) o.fused_steps = in->fused_steps;
   }
-#ifdef HG_TUNING
-  if (const char *e = getenv("HG_HUB_THREADS")) o.hub_threads = atoi(e) == 512 ? 512 : 1024;
-#endif
   if (o.short_max > o.panel_nnz || o.split_len < o.short_max || o.panel_rows > 4096 ||
       o.panel_nnz > 16384 || o.fused_tile_bytes > 131072) {
     hg::set_error("hg_plan_opts: need short_max <= panel_nnz <= 16384, split_len >= short_max, panel_rows <= 4096, fused_tile_bytes <= 131072");
@@ -688,9 +685,6 @@ int hg_plan_create_device(hg_plan **out, int32_t N, int32_t M, int64_t nnz,
 
 void hg_plan_destroy(hg_plan *p) {
   if (!p) return;
-  if (p->ev_fork) (void)hipEventDestroy(static_cast<hipEvent_t>(p->ev_fork));
-  if (p->ev_join) (void)hipEventDestroy(static_cast<hipEvent_t>(p->ev_join));
-  if (p->side_stream) (void)hipStreamDestroy(static_cast<hipStream_t>(p->side_stream));
   if (p->d_ptr_v) (void)hipFree(p->d_ptr_v);
   if (p->d_ind_v) (void)hipFree(p->d_ind_v);
   for (int h = 0; h < 2; h++) sched_free(p->sched[h]);
@@ -1021,33 +1015,6 @@ int hg_scatter_record_f32(int32_t N, int32_t M, int32_t F, const float *T, const
   return HG_OK;
 }
 
-static bool two_stream_wanted() {
-#ifdef HG_TUNING
-  static const bool on = [] { const char *e = getenv("HG_TWO_STREAM"); return e && atoi(e) != 0; }();
-  return on;
-#else
-  return false;
-#endif
-}
-
-// The plan's side stream and its fork / join events, created on first use.
-static int side_stream(const hg_plan *cp, hipStream_t *out) {
-  hg_plan *p = const_cast<hg_plan *>(cp);
-  std::lock_guard<std::mutex> lock(p->side_mu);
-  if (!p->side_stream) {
-    hipStream_t st = nullptr;
-    hipEvent_t a = nullptr, b = nullptr;
-    HG_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    HG_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming));
-    HG_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
-    p->side_stream = st;
-    p->ev_fork = a;
-    p->ev_join = b;
-  }
-  *out = static_cast<hipStream_t>(p->side_stream);
-  return HG_OK;
-}
-
 // Shared body of hg_aggr_fused_f32 and hg_aggr_linear_f32.  With lin != nullptr the caller
 // wants (aggregated rows) * Wlin^T in lin->Y: the fused panels do that in their epilogue when
 // they can (lin->done = true); otherwise the aggregated rows go to Y as usual and the caller
@@ -1126,7 +1093,6 @@ static int aggr_impl(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
       return HG_ERR_WORKSPACE;
     }
     float *partial = reinterpret_cast<float *>(ws + fc.part);
-    hipStream_t hub_side = nullptr;
     // scales pre-gathered into panel order, if the caller bound exactly these arrays
     const bool bound = (degE || degV || W) && f->bound_degE == degE && f->bound_W == W && f->bound_degV == degV;
     if (bound && W && f->bound_W_is_one) W = nullptr;  // multiplying by exactly 1.0f is the identity: same bits, less work
@@ -1172,7 +1138,6 @@ static int aggr_impl(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
       h.vslot0 = f->hub.d_vslot0;
       h.nwg = f->hub.nwg;
       h.ng = f->hub.ng;
-      h.bs = f->hub.bs;
       h.cap = f->hub.cap;
       h.max_rec_words = f->hub.max_rec_words;
       h.X = X;
@@ -1187,20 +1152,8 @@ static int aggr_impl(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
       h.nrows_mat = f->n_mat;
       h.n_heavy = f->hub.n_heavy;
       for (int q = 0; q < hg::kHubHeavy; q++) h.hslot0[q] = f->hub.hslot0[q];
-      // The hub pass and the vertex panels share no output row.  Forked onto the plan's side stream the pass runs beside
-      // the panels and is joined before the fixups (event record / wait: capturable).  Diagnostic build, HG_TWO_STREAM=1.
-      if (two_stream_wanted()) {
-        if ((rc = side_stream(plan, &hub_side)) != HG_OK) return rc;
-        hipEvent_t fork = static_cast<hipEvent_t>(plan->ev_fork);
-        hipError_t e = hipEventRecord(fork, s);
-        if (e == hipSuccess) e = hipStreamWaitEvent(hub_side, fork, 0);
-        if (e == hipSuccess) e = hg::launch_hub_pass(h, vec4, hub_side);
-        if (e == hipSuccess) e = hipEventRecord(static_cast<hipEvent_t>(plan->ev_join), hub_side);
-        if (e != hipSuccess) return hip_fail("hub_pass launch (side stream)", e);
-      } else {
-        hipError_t e = hg::launch_hub_pass(h, vec4, s);
-        if (e != hipSuccess) return hip_fail("hub_pass launch", e);
-      }
+      hipError_t e = hg::launch_hub_pass(h, vec4, s);
+      if (e != hipSuccess) return hip_fail("hub_pass launch", e);
     }
     // (c) everything else: vertex panels with the hyperedge sums staged in LDS
     hg::FusedArgs a;
@@ -1245,10 +1198,6 @@ static int aggr_impl(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
     }
     hipError_t e = hg::launch_fused(a, vec4, s);
     if (e != hipSuccess) return hip_fail("fused_panel launch", e);
-    if (hub_side) {  // join: the fixups read the hub pass's partial rows
-      e = hipStreamWaitEvent(s, static_cast<hipEvent_t>(plan->ev_join), 0);
-      if (e != hipSuccess) return hip_fail("hub_pass join", e);
-    }
     // (d) hubs and split vertices: Y[v] = degV[v] * (sum of the vertex's partial rows), fixed order
     if (!f->fixups.empty()) {
       e = hg::launch_fixups(f->d_fixups, (int)f->fixups.size(), f->n_fix_l1, F, partial, Y, degV, nullptr, nullptr, vec4, s, rows_whole_64(Y, F));

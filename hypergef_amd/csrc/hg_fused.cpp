@@ -43,9 +43,9 @@ void classify_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *p
 }
 
 // Geometry of the hub pass for a tile row of `row_floats` floats: 1024 threads, LPR lanes per row.
-static void hub_geometry(int32_t ng_panel, int32_t row_floats, int32_t tile_bytes, int32_t threads, HubPass &h) {
-  h.bs = threads == 512 ? 512 : 1024;
-  h.ng = ng_panel * (h.bs / 256);  // bs / LPR where ng_panel = 256 / LPR
+static void hub_geometry(int32_t ng_panel, int32_t row_floats, int32_t tile_bytes, HubPass &h) {
+  h.bs = 1024;
+  h.ng = ng_panel * 4;  // 1024 / LPR where ng_panel = 256 / LPR
   h.R = kHubRows;
   h.cap = std::max(16, std::min(1024, tile_bytes / (row_floats * 4))) / 16 * 16;
   h.cap = std::max(h.cap, (h.ng + 15) / 16 * 16);  // the end-of-launch reduction parks one row per lane group in the tile
@@ -180,7 +180,7 @@ void build_fused(int32_t N, int32_t M, const int32_t *ptr_t, const int32_t *ind_
   }
   std::vector<int32_t> hub_of((size_t)N, -1), parts;
   HubPass &hp = f.hub;
-  hub_geometry(ng, row_floats, o.hub_tile_bytes, o.hub_threads, hp);
+  hub_geometry(ng, row_floats, o.hub_tile_bytes, hp);
   const int32_t kHubMinDeg = o.hub_min_deg;
   // one hyperedge of t_big members and a pair for every hub must fit an empty round's record
   allow_hub = allow_hub && hub_rec_bound(hp, f.t_big, f.t_big, 1, hp.ng * hp.R) <= kHubRecWords;

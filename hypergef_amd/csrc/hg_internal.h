@@ -205,7 +205,6 @@ struct Opts {
   // hub pass (not in the C ABI; the host tests lower them to reach that code on small graphs)
   int64_t hub_min_nnz = 1 << 20;  // smaller graphs are launch-bound: no extra pass
   int32_t hub_min_deg = 256;      // below this a hub's partial rows cost more than pieces do
-  int32_t hub_threads = 1024;     // threads of a hub-pass workgroup (diagnostic build: 512 leaves half the register file to panel workgroups)
   int32_t hub_tile_bytes = 80 * 1024;  // LDS tile of a hub-pass round (of the CU's 160 KiB; the rest: two records, scales)
 };
 
@@ -263,10 +262,6 @@ struct hg_plan {
   std::map<int64_t, int32_t> auto_choice;  // what HG_VARIANT_AUTO resolved to, keyed by (F, vec4)
   std::map<int32_t, int32_t> hop_kernel;   // per F, set by hg_plan_tune_f32: k0 + 3 * k1, kernel of each pull hop (hg_tune_info)
   std::mutex auto_mu;
-  // a second stream of the plan's own and the events that fork work onto it and join it back (the hub pass beside the
-  // vertex panels; hg_api.hip, side_stream).  void*: this header does not see the HIP runtime.
-  void *side_stream = nullptr, *ev_fork = nullptr, *ev_join = nullptr;
-  std::mutex side_mu;
   double small_nnz_frac = 0.0;  // share of incidences in hyperedges of <= t_big members
   int64_t device_bytes = 0;
   int device = -1;

@@ -48,7 +48,6 @@ struct FusedArgs {
   int32_t max_rec_words;  // LDS space for one record
   int32_t ng;             // lane groups the records were packed for
   int32_t cap, rows_cap;  // LDS tile rows (hyperedge slots) and rows per panel
-  int32_t stagger = 0;    // persistent epilogue workgroups: start delay per CU slot, units of 1024 cycles
   const float *X, *Xe_mat, *degE, *W, *degV;
   const float *bsA, *bsB, *bsD;  // bound scales in panel order (or null: gather from degE/W/degV)
   float *Y;
@@ -86,7 +85,6 @@ struct HubArgs {
   const int32_t *wg_first;  // [nwg + 1] rounds of each workgroup
   const int32_t *vslot0;    // [ng * R] first partial row of each virtual row, -1 = unused
   int32_t nwg, ng, cap, max_rec_words;
-  int32_t bs = 1024;        // threads per workgroup the records were packed for (ng = bs / lanes per row)
   const float *X, *Xe_mat, *degE, *W;
   float *partial;
   int32_t F;

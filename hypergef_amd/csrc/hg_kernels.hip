@@ -671,139 +671,6 @@ __device__ __forceinline__ void panel_times_wt_staged_chunked(float *t, int nrow
   HG_STAMP(11);
 }
 
-// K = 128, staged-only instances (round 4).  The chunked phase above keeps ONE chunk of 8 k-steps in flight behind the
-// chunk that feeds the matrix pipe: 16 MFMAs = 512 cycles of cover for an L2 round trip of a thousand cycles and more
-// under load, eight times per panel and wave.  Here the wave's B fragments travel through a ring of D chunk buffers
-// (8 registers each): chunks 0 .. D-1 of the first column tile are loaded ahead of the phase (before the barriers that
-// precede it), and as soon as a chunk's MFMAs have issued, the chunk D places further on -- this column tile's or the
-// next one's -- is loaded into its registers: every load has D - 1 chunks' MFMAs to land.  D = 3 fits the budget of
-// six waves per SIMD, which is what the LDS tile of the epilogue's schedule allows (a whole column tile, D = 4, needs
-// 96 registers: five waves, one workgroup per CU fewer, 10 % slower on the same box -- profiles/r04_experiments.md).
-#ifndef HG_LIN_RING
-#define HG_LIN_RING 0  // 0: off (the chunked phase above).  Measured on one box against it, pubmed x64 128 -> 128: D = 4 at
-#endif                 // five waves per SIMD +10 %, D = 3 and D = 2 at six +4..5 % (profiles/r04_experiments.md): not shipped.
-constexpr int ring_rpn(int npw) { return 4 / npw > 2 ? 2 : 4 / npw; }  // row tiles per column tile and wave: K = 128 panels have two at most
-template <int KSTEPS, int NPW, int NRT, int D>
-__device__ __forceinline__ void mfma_rows_ring(const float *ta, int tstep, const float *Wlin, const LinSplit &sp, int NT,
-                                               int lane, float (&b)[D * 8], hg_f4 *acc) {
-  constexpr int RPN = ring_rpn(NPW), CH = 8, NCH = KSTEPS / CH;
-  static_assert(D >= 1 && D <= NCH, "ring of up to NCH chunks");
-#pragma unroll
-  for (int ni = 0; ni < NPW; ni++) {
-    const int nt = sp.nt_first + ni * sp.nt_step;
-    if (nt < NT) {  // wave-uniform
-      float a0[NRT], a1[NRT], a2[NRT];
-#pragma unroll
-      for (int j = 0; j < NRT; j++) {
-        a0[j] = ta[j * tstep];
-        a1[j] = ta[j * tstep + 4];
-      }
-#pragma unroll
-      for (int c = 0; c < NCH; c++) {
-        const int q = ni * NCH + c, slot = q % D;  // constants after unrolling
-#pragma unroll
-        for (int k8 = 0; k8 < CH; k8++) {
-          const int ks = c * CH + k8;
-          if (ks + 2 < KSTEPS) {
-#pragma unroll
-            for (int j = 0; j < NRT; j++) a2[j] = ta[j * tstep + (ks + 2) * 4];
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int j = 0; j < NRT; j++)
-            acc[ni * RPN + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b[slot * CH + k8], acc[ni * RPN + j], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int j = 0; j < NRT; j++) {
-            a0[j] = a1[j];
-            a1[j] = a2[j];
-          }
-        }
-        // this chunk's registers are free: chunk q + D lands in them
-        const int q2 = q + D, ni2 = q2 / NCH, c2 = q2 % NCH;
-        const int nt2 = sp.nt_first + ni2 * sp.nt_step;
-        if (ni2 < NPW && nt2 < NT) {  // wave-uniform
-          const float4 *w = reinterpret_cast<const float4 *>(Wlin) + ((int64_t)nt2 * (KSTEPS / 4) + 2 * c2) * 64 + lane;
-          const float4 f0 = w[0], f1 = w[64];
-          b[slot * CH + 0] = f0.x; b[slot * CH + 1] = f0.y; b[slot * CH + 2] = f0.z; b[slot * CH + 3] = f0.w;
-          b[slot * CH + 4] = f1.x; b[slot * CH + 5] = f1.y; b[slot * CH + 6] = f1.z; b[slot * CH + 7] = f1.w;
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    }
-  }
-}
-
-// chunks 0 .. D-1 of column tile nt: what mfma_rows_ring expects in its ring when it starts
-template <int KSTEPS, int D>
-__device__ __forceinline__ void load_bfrag_ring(const float *wfrag, int nt, int lane, float (&b)[D * 8]) {
-  const float4 *w = reinterpret_cast<const float4 *>(wfrag) + (int64_t)nt * (KSTEPS / 4) * 64 + lane;
-#pragma unroll
-  for (int q = 0; q < 2 * D; q++) {
-    const float4 f = w[q * 64];
-    b[q * 4 + 0] = f.x;
-    b[q * 4 + 1] = f.y;
-    b[q * 4 + 2] = f.z;
-    b[q * 4 + 3] = f.w;
-  }
-}
-
-// The staged form (see panel_times_wt_staged) on the ring matrix phase.  b: the ring, filled by load_bfrag_ring.
-template <int KSTEPS, int NPW, int D>
-__device__ __forceinline__ void panel_times_wt_staged_ring(float *t, int nrows, int F_out, const float *Wlin,
-                                                           const int32_t *rowmap, float *Y, int tid, float (&b)[D * 8],
-                                                           int relu, Stamper &stp) {
-  constexpr int K = KSTEPS * 4, LD = K + 4, RPN = ring_rpn(NPW);
-  const int lane = tid & 63;
-  const int NT = F_out >> 4, RT = (nrows + 15) >> 4;
-  const LinSplit sp = lin_split(tid >> 6, NT);
-  hg_f4 acc[NPW * RPN];
-#pragma unroll
-  for (int j = 0; j < NPW * RPN; j++) acc[j] = hg_f4{0.f, 0.f, 0.f, 0.f};
-  int nrt = 0;
-  if (sp.active) {
-    nrt = min(RPN, max(0, (RT - sp.rt_first + sp.rt_step - 1) / sp.rt_step));
-    const float *ta = t + (sp.rt_first * 16 + (lane & 15)) * LD + (lane >> 4);
-    const int tstep = sp.rt_step * 16 * LD;
-    // K = 128 panels hold at most 4 rows per lane group x 8 lane groups = two row tiles (launcher): nrt <= 2.  The three-
-    // and four-tile forms are not compiled in -- their A-fragment registers were what spilled at this budget.
-    switch (nrt) {  // wave-uniform
-      case 2: if constexpr (RPN >= 2) mfma_rows_ring<KSTEPS, NPW, 2, D>(ta, tstep, Wlin, sp, NT, lane, b, acc); break;
-      case 1: mfma_rows_ring<KSTEPS, NPW, 1, D>(ta, tstep, Wlin, sp, NT, lane, b, acc); break;
-      default: break;
-    }
-  }
-  HG_STAMP(8);
-  __syncthreads();  // every wave has read its A fragments: the rows can be overwritten
-  HG_STAMP(9);
-  if (sp.active) {
-#pragma unroll
-    for (int ni = 0; ni < NPW; ni++) {
-      const int nt = sp.nt_first + ni * sp.nt_step;
-      if (nt < NT) {
-#pragma unroll
-        for (int j = 0; j < RPN; j++)
-          if (j < nrt) {
-            float *d = t + ((sp.rt_first + j * sp.rt_step) * 16 + 4 * (lane >> 4)) * LD + nt * 16 + (lane & 15);
-#pragma unroll
-            for (int i = 0; i < 4; i++) d[i * LD] = acc[ni * RPN + j][i];
-          }
-      }
-    }
-  }
-  __syncthreads();
-  HG_STAMP(10);
-  const int q = F_out >> 2;  // float4 pieces per row
-  for (int i = tid; i < nrows * q; i += 256) {
-    const int r = i / q, c = (i - r * q) * 4;
-    float4 o = *reinterpret_cast<const float4 *>(t + r * LD + c);
-    if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
-    if (HG_Y_NT) Vec<4>{o}.store_nt(Y + (int64_t)rowmap[r] * F_out + c);
-    else *reinterpret_cast<float4 *>(Y + (int64_t)rowmap[r] * F_out + c) = o;
-  }
-  HG_STAMP(11);
-}
-
 // WIDE = false: the caller guarantees the staged form applies (F_out <= K and few enough row tiles); the direct form
 // for wider outputs is then not compiled in -- its registers would set the budget of the whole kernel.
 template <int KSTEPS, bool WIDE = true>
@@ -1051,18 +918,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *partial,
 #ifndef HG_LIN_WAVES_STAGED32
 #define HG_LIN_WAVES_STAGED32 6
 #endif
-#ifndef HG_LIN_PERSIST
-#define HG_LIN_PERSIST 0  // 1: linear-epilogue instances as one resident round of workgroups walking their panels (fused_packed_kernel).
-                          // Measured, same box: pubmed x64 128 -> 128 0.644 -> 0.672 ms, cora x1024 64 -> 64 0.475 -> 0.570; fewer panels
-                          // per workgroup (12 / 24 rounds of workgroups) converge back to the one-panel figure; staggered starts: no
-                          // change (profiles/r04_experiments.md).  Off.
-#endif
 #ifndef HG_LIN_MERGE_PHASES
 #define HG_LIN_MERGE_PHASES 1  // K = 128 staged epilogue instances: hop 1's two phases as one run of batches (with twelve gathers in
                                // flight at the six-wave budget: -1.2 % on pubmed x64 128 -> 128, -2.2 % on 128 -> 64, same box, three rounds)
-#endif
-#ifndef HG_LIN_HOP2_BATCH
-#define HG_LIN_HOP2_BATCH 0
 #endif
 #ifndef HG_LIN_U32
 #define HG_LIN_U32 12  // row gathers in flight per lane, K = 128 staged instances
@@ -1096,29 +954,25 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
   using V = Vec<VEC>;
   extern __shared__ int32_t smem[];
   const int64_t F = a.F;
-  // PERSIST (linear-epilogue instances, HG_LIN_PERSIST = 1: experiment, off): the grid is one resident round of workgroups
-  // and each walks its share of the panels in a loop.  Phase stamps count about 4.2 workgroups' worth of in-code time in
-  // flight per CU where six are resident: the rest of a slot's time passes between one workgroup's end and the next
-  // one's first instruction.  Closing that gap this way did not pay (see HG_LIN_PERSIST), as for the plain panels in round 2.
-  constexpr bool PERSIST = LIN && (HG_LIN_PERSIST != 0);
-  const int cpx = a.npanels >> 3, rem = a.npanels & 7;
-  // workgroups are dealt round-robin to the 8 XCDs; each XCD owns one contiguous run of panels (neighbouring panels share
-  // an L2).  After a substantial materialisation pre-pass the run is walked backwards: the pre-pass walked the hyperedges
-  // forwards, so the member rows it read last -- still in the L2 / Infinity Cache -- are the ones the panels ask for
-  // first (pubmed-shape batches at F = 64 .. 128: -2 .. -3.6 % per step; neutral elsewhere).
-  const int xcd = a.xcd_remap ? (int)(blockIdx.x & 7) : 0;
-  const int run_len = a.xcd_remap ? cpx + (xcd < rem ? 1 : 0) : a.npanels;
-  const int run0 = a.xcd_remap ? xcd * cpx + (xcd < rem ? xcd : rem) : 0;
-  const int i_first = a.xcd_remap ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-  const int i_step = PERSIST ? (a.xcd_remap ? (int)(gridDim.x >> 3) : (int)gridDim.x) : run_len;  // not PERSIST: one panel
-  HG_STAMP_INIT(true);
-  if constexpr (PERSIST) {
-    // The resident round starts all at once and every panel takes about as long as the next: left alone the workgroups of
-    // a CU stay in step -- all in hop 1 together, all at the matrix pipe together.  Each CU slot starts a little later
-    // than the one before (the dispatcher deals a round of 32 workgroups per XCD across its 32 CUs).
-    const int slot = (int)((blockIdx.x >> 3) >> 5) & 7;
-    for (int k = 0; k < slot * a.stagger; k++) __builtin_amdgcn_s_sleep(16);  // 1024 cycles each; a fixed, finite count
+  const int tid = threadIdx.x;
+  const int gl = tid & (LPR - 1);
+  const int lcol = gl * VEC;
+  const int col = blockIdx.y * TW + lcol;
+  const bool col_ok = col < a.F;
+  int b = blockIdx.x;
+  if (a.xcd_remap) {
+    // workgroups are dealt round-robin to the 8 XCDs; give each XCD one contiguous run of panels so that neighbouring
+    // panels share an L2
+    const int x = b & 7;
+    int i = b >> 3;
+    const int cpx = a.npanels >> 3, rem = a.npanels & 7;
+    // After a substantial materialisation pre-pass each XCD walks its run of panels backwards: the pre-pass walked the
+    // hyperedges forwards, so the member rows it read last -- still in the L2 / Infinity Cache -- are the ones the
+    // panels ask for first (pubmed-shape batches at F = 64 .. 128: -2 .. -3.6 % per step; neutral elsewhere).
+    if (MAT && a.reverse_runs) i = cpx + (x < rem ? 1 : 0) - 1 - i;
+    b = x * cpx + (x < rem ? x : rem) + i;
   }
+  HG_STAMP_INIT(true);
 
   float *tile = reinterpret_cast<float *>(smem);        // [cap * TW]  (LIN: [cap * (TW + 4)])
   int32_t *rec = smem + a.cap * (LIN ? TW + 4 : TW);     // [max_rec_words], 16-byte aligned
@@ -1127,17 +981,6 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
   float *sB = sA + a.cap;                                // [cap]
   float *sdeg = (a.degE || a.W) ? sB + a.cap : sA;       // [rows_cap]
 
-  auto run_panel = [&](const int b) {
-  // PERSIST: everything derived from the thread index is recomputed per panel from an opaque copy -- left alone the
-  // compiler hoists all of it (lane addresses of the tile, the operand rows, the B fragments ...) out of the panel loop
-  // and keeps it live across the whole body: 100-230 bytes of scratch per lane.
-  int tid_ = threadIdx.x;
-  if constexpr (PERSIST) asm volatile("" : "+v"(tid_));
-  const int tid = tid_;
-  const int gl = tid & (LPR - 1);
-  const int lcol = gl * VEC;
-  const int col = blockIdx.y * TW + lcol;
-  const bool col_ok = col < a.F;
   const FRec rt = a.rec_tab[b];
   HG_STAMP(0);
   const int32_t *grec = a.rec + rt.off;
@@ -1292,61 +1135,13 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
   __syncthreads();
   HG_STAMP(4);
   if constexpr (LIN) {  // ---- hop 2 into registers, then rows * Wlin^T on the matrix cores
-    // The B fragments of this wave's first column tile are issued after hop 2 and fly across the two barriers that follow
-    // (before hop 2 they would sit in registers through it: spills).  RING (K = 128, staged only): the whole column tile
-    // (mfma_rows_ring); the others: what BPre says.
-    constexpr bool RING = HG_LIN_RING > 0 && !LINW && TW / 4 >= 32;
-    constexpr int RD = HG_LIN_RING > 0 ? HG_LIN_RING : 1;
-    float bv[RING ? RD * 8 : BPre<TW / 4>::N];
+    // the B fragments of this wave's first column tile are issued after hop 2 and fly across the two barriers that
+    // follow (issued before hop 2 they would hold K/4 more registers through it: 78 instead of 64 VGPRs)
+    float bv[BPre<TW / 4>::N];
     const LinSplit sp = lin_split(tid >> 6, a.F_out >> 4);
     const int rpg = (nrows + NG - 1) / NG;  // <= 4 (launcher)
     const int r0 = min(g * rpg, nrows), r1 = min(r0 + rpg, nrows);
     V outr[4];
-#if HG_LIN_HOP2_BATCH
-    // The lane group's (up to) four rows are walked together: their list ends in one LDS round trip, then per step the
-    // four slot ids and the four tile rows in flight at once -- row after row the same reads are a chain of some twenty
-    // dependent LDS latencies, 18 % of a workgroup's life at F = 128 (phase stamps).  Each row still adds its slots in
-    // list order: same bits.  The trip count is the wave's longest list (wave-uniform); a step past a row's end re-reads
-    // slot 0 and is not added.
-    // Every LDS read below is unconditional, at a clamped position, and masked afterwards: a conditional read becomes a
-    // branch with its own s_waitcnt, which is the serial chain again.
-    int pb_[4], n_[4], len = 0;
-    {
-      const int rl = max(nrows - 1, 0);
-      int e_[5];  // list ends of rows r0 - 1 .. r0 + 3 (clamped)
-#pragma unroll
-      for (int i = 0; i < 5; i++) e_[i] = (int)pend[min(max(r0 + i - 1, 0), rl)];
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        outr[i] = V::zero();
-        const int r = r0 + i;
-        const int okm = -(int)(r < r1);                 // all ones / zero
-        pb_[i] = e_[i] & okm & -(int)(r > 0);
-        n_[i] = (e_[i + 1] & okm) - pb_[i];
-        len = max(len, n_[i]);
-      }
-    }
-    const int last = max((int)pend[max(nrows - 1, 0)] - 1, 0);  // last valid position of the slot-id list
-    for (int k = 0; __builtin_amdgcn_ballot_w64(k < len) != 0; k++) {
-      int sidx[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++) sidx[i] = (int)pvs[min(pb_[i] + k, last)] & -(int)(k < n_[i]);
-      V t[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++) t[i] = V::load(tile + sidx[i] * TW + lcol);
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-        if (k < n_[i]) outr[i].add(t[i]);
-    }
-    if (a.degV) {
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-        if (n_[i] > 0) outr[i].mul(sdeg[r0 + i]);
-    }
-#else
-    // row after row.  (HG_LIN_HOP2_BATCH = 1 walks the lane group's four rows together -- list ends in one LDS round trip,
-    // four slot ids and four tile rows in flight per step, every read unconditional and masked: measured 4-5 % SLOWER on
-    // the pubmed x64 128 -> 128 batch with the B ring, same box; profiles/r04_experiments.md.)
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       outr[i] = V::zero();
@@ -1357,7 +1152,6 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
         if (a.degV && pe > pb) outr[i].mul(sdeg[r]);
       }
     }
-#endif
     if (a.epi.R || a.epi.ca != 1.f) {  // t' = ca * t + cb * R[v]  (workgroup-uniform)
       const float cb = a.epi.cb_dev ? *a.epi.cb_dev : a.epi.cb;
 #pragma unroll
@@ -1371,10 +1165,7 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
           }
         }
     }
-    if (sp.active && !(DBG && (a.debug & 512))) {
-      if constexpr (RING) load_bfrag_ring<TW / 4, RD>(a.Wlin, sp.nt_first, tid & 63, bv);
-      else load_bfrag_pre<TW / 4>(a.Wlin, sp.nt_first, tid & 63, bv);
-    }
+    if (sp.active && !(DBG && (a.debug & 512))) load_bfrag_pre<TW / 4>(a.Wlin, sp.nt_first, tid & 63, bv);
     HG_STAMP(5);
     __syncthreads();  // every slot row has been read: the tile becomes the [rows][TW + 4] operand
 #pragma unroll
@@ -1400,12 +1191,8 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
       }
     }
     HG_STAMP(7);
-    if constexpr (RING) {
-      if (a.F_out > 64) panel_times_wt_staged_ring<TW / 4, 2, RD>(tile, nrows, a.F_out, a.Wlin, prow, a.Y, tid, bv, a.epi.relu, stp);
-      else panel_times_wt_staged_ring<TW / 4, 1, RD>(tile, nrows, a.F_out, a.Wlin, prow, a.Y, tid, bv, a.epi.relu, stp);
-    } else {
-      panel_times_wt<TW / 4, LINW>(tile, nrows, a.F_out, a.Wlin, prow, 0, a.Y, tid, bv, a.epi.relu, stp);
-    }
+    panel_times_wt<TW / 4, LINW>(tile, nrows, a.F_out, a.Wlin, prow, 0, a.Y, tid, bv, a.epi.relu, stp);
+    HG_STAMP_FLUSH();
     return;
   } else if (!(DBG && (a.debug & 8))) {  // ---- hop 2
     const int rpg = (nrows + NG - 1) / NG;
@@ -1425,14 +1212,6 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
     }
   }
   HG_STAMP(5);
-  };  // run_panel
-
-  for (int i = i_first; i < run_len; i += i_step) {
-    const int ii = (MAT && a.reverse_runs && a.xcd_remap) ? run_len - 1 - i : i;
-    run_panel(run0 + ii);
-    if constexpr (!PERSIST) break;
-    lds_barrier();  // every wave is done with the tile and the record (its last LDS reads fed the row stores): next panel
-  }
   HG_STAMP_FLUSH();
 }
 
@@ -1461,9 +1240,9 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
 #else
 #define HG_HUB_ABLATE(bit) false
 #endif
-template <int LPR, int VEC, int U, bool MAT, bool SCALED, bool HEAVY, int BS = 1024>
-__global__ __launch_bounds__(BS) void hub_pass_kernel(const HubArgs a) {
-  constexpr int NG = BS / LPR, TW = LPR * VEC, R = kHubRows, NH = HEAVY ? kHubHeavy : 1;
+template <int LPR, int VEC, int U, bool MAT, bool SCALED, bool HEAVY>
+__global__ __launch_bounds__(1024) void hub_pass_kernel(const HubArgs a) {
+  constexpr int BS = 1024, NG = BS / LPR, TW = LPR * VEC, R = kHubRows, NH = HEAVY ? kHubHeavy : 1;
   using V = Vec<VEC>;
   extern __shared__ int32_t smem[];
   const int tid = threadIdx.x;
@@ -1495,7 +1274,7 @@ __global__ __launch_bounds__(BS) void hub_pass_kernel(const HubArgs a) {
   HG_STAMP_INIT(true);
   // A record is at most NPRE * 16 KB: each thread carries NPRE dwordx4 of the NEXT round's record
   // through hop 1, so the copy's round trip hides behind the row gathers.
-  constexpr int NPRE = (6144 * 4 + BS * 16 - 1) / (BS * 16);  // a record is at most 6144 words (kHubRecWords, hg_fused.cpp)
+  constexpr int NPRE = 2;
   hg_i4 pre[NPRE];
   auto fetch = [&](int rd) {
     const HubRec rt = a.rec_tab[rd];
@@ -1862,30 +1641,6 @@ static hipError_t launch_lds(dim3 grid, size_t lds, hipStream_t stream, const Ar
   return hipGetLastError();
 }
 
-// One resident round of workgroups for a persistent kernel: (what the runtime says fits a CU) x CUs, a multiple of 8 (one
-// share per XCD), at least 8 and no more than `work` rounded up to 8.  Asked once per kernel instance and LDS size.
-template <auto Kern, int BLOCK = 256>
-static unsigned resident_grid(size_t lds, int work) {
-  static std::atomic<size_t> known_lds{(size_t)-1};
-  static std::atomic<int> known{0};
-  int per_cu = known.load(std::memory_order_relaxed);
-  if (known_lds.load(std::memory_order_relaxed) != lds || per_cu <= 0) {
-    int n = 0, cus = 0, dev = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(Kern), BLOCK, lds) != hipSuccess || n <= 0) n = 1;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-      cus = 256;
-    per_cu = n * cus;
-    known.store(per_cu, std::memory_order_relaxed);
-    known_lds.store(lds, std::memory_order_relaxed);
-  }
-#ifdef HG_TUNING
-  static const int force = [] { const char *e = getenv("HG_LIN_PERSIST_PER_CU"); return e ? atoi(e) : 0; }();
-  if (force > 0) per_cu = force * 256;  // diagnostic build: workgroups per CU of the resident round
-#endif
-  const int want = std::min(per_cu, (work + 7) / 8 * 8);
-  return (unsigned)std::max(8, want / 8 * 8);
-}
-
 template <int LPR, int VEC>
 static hipError_t launch_fixups_t(const GatherArgs &a, int nfix, int nfix_l1, const Fixup *fixups, hipStream_t stream) {
   const int col_tiles = (a.F + LPR * VEC - 1) / (LPR * VEC);
@@ -2008,27 +1763,14 @@ size_t hub_pass_lds_bytes(int32_t cap, int32_t row_floats, int32_t max_rec_words
 template <int LPR>
 static hipError_t launch_hub_t(const HubArgs &a, hipStream_t stream) {
   constexpr int TW = LPR * 4;
-  if (a.ng != a.bs / LPR || (a.bs != 1024 && a.bs != 512)) return hipErrorInvalidValue;  // records were packed for another lane layout
+  if (a.ng != 1024 / LPR) return hipErrorInvalidValue;  // records were packed for another lane layout
   const bool fast = a.x_bytes > 0 && a.nrows_x < (1 << 24) && a.F < (1 << 22) &&
                     (!a.Xe_mat || (a.mat_bytes > 0 && a.nrows_mat < (1 << 24)));
   if (!fast) return hipErrorInvalidValue;  // the plan builds a hub pass only for buffer-addressable tables
   const dim3 grid(a.nwg, (a.F + TW - 1) / TW);
   const size_t lds = hub_pass_lds_bytes(a.cap, TW, a.max_rec_words);
-  if (a.cap < a.bs / LPR) return hipErrorInvalidValue;  // the end-of-launch reduction parks one row per lane group in the tile
+  if (a.cap < 1024 / LPR) return hipErrorInvalidValue;  // the end-of-launch reduction parks one row per lane group in the tile
   const int spec = (a.Xe_mat ? 1 : 0) | ((a.degE || a.W) ? 2 : 0) | (a.n_heavy > 0 ? 4 : 0);
-#ifdef HG_TUNING
-  // diagnostic build: 512-thread workgroups (half the register file, so panel workgroups fit beside a hub workgroup),
-  // compiled for the power-law bench configuration's lane layout only
-  if (a.bs == 512) {
-    if constexpr (LPR == 16) {
-      if (spec == 5) return launch_lds<hub_pass_kernel<LPR, 4, 4, true, false, true, 512>, 512>(grid, lds, stream, a);
-      if (spec == 7) return launch_lds<hub_pass_kernel<LPR, 4, 4, true, true, true, 512>, 512>(grid, lds, stream, a);
-    }
-    return hipErrorInvalidValue;
-  }
-#else
-  if (a.bs != 1024) return hipErrorInvalidValue;
-#endif
 #define HG_HUB(M, S, H) return launch_lds<hub_pass_kernel<LPR, 4, 4, M, S, H>, 1024>(grid, lds, stream, a)
   switch (spec) {
     case 0: HG_HUB(false, false, false);
@@ -2082,10 +1824,6 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
   const Tuning &t = tuning();
   FusedArgs ad = a;
   ad.debug = t.fused_debug;
-#ifdef HG_TUNING
-  static const int stagger = [] { const char *e = getenv("HG_LIN_STAGGER"); return e ? atoi(e) : 0; }();
-  ad.stagger = std::max(0, std::min(stagger, 64));
-#endif
   const dim3 grid(a.npanels, col_tiles);
   // tile | record | scale staging (only what this call's scales need: without them the F = 32
   // bench shape fits 8 workgroups per CU instead of 7)
@@ -2105,17 +1843,12 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
         // K = 128, staged: the LDS tile already holds occupancy to five workgroups per CU, so the registers for twelve row
         // gathers in flight per lane cost nothing there (a panel's hop 1 is then two dependent batches instead of three)
         constexpr int UL = LPR >= 32 ? HG_LIN_U32 : 8;
-        // HG_LIN_PERSIST: one resident round of workgroups, each walking its share of the panels (fused_packed_kernel)
-#define HG_PKG(KERN) (HG_LIN_PERSIST ? dim3(resident_grid<KERN>(lds_l, a.npanels), col_tiles) : grid)
 #define HG_PKL(M, S)                                                                                                          \
-  return staged ? launch_lds<fused_packed_kernel<LPR, VEC, UL, true, M, S, false, true, 256, false>>(                         \
-                      HG_PKG((fused_packed_kernel<LPR, VEC, UL, true, M, S, false, true, 256, false>)), lds_l, stream, ad)    \
-                : launch_lds<fused_packed_kernel<LPR, VEC, 8, true, M, S, false, true, 256, true>>(                           \
-                      HG_PKG((fused_packed_kernel<LPR, VEC, 8, true, M, S, false, true, 256, true>)), lds_l, stream, ad)
+  return staged ? launch_lds<fused_packed_kernel<LPR, VEC, UL, true, M, S, false, true, 256, false>>(grid, lds_l, stream, ad) \
+                : launch_lds<fused_packed_kernel<LPR, VEC, 8, true, M, S, false, true, 256, true>>(grid, lds_l, stream, ad)
 #ifdef HG_TUNING
         if (t.fused_debug & (768 | 1 | 32))  // ablations of the matrix phase / the gathers (tools/linear_probe.py): diagnostic build only
-          return launch_lds<fused_packed_kernel<LPR, VEC, 8, true, true, true, true, true>>(
-              HG_PKG((fused_packed_kernel<LPR, VEC, 8, true, true, true, true, true>)), lds_l, stream, ad);
+          return launch_lds<fused_packed_kernel<LPR, VEC, 8, true, true, true, true, true>>(grid, lds_l, stream, ad);
 #endif
         switch (spec) {
           case 0: HG_PKL(false, false);
@@ -2124,7 +1857,6 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
           default: HG_PKL(true, true);
         }
 #undef HG_PKL
-#undef HG_PKG
       } else {
         return hipErrorInvalidValue;
       }

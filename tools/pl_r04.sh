@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round 4, power-law config (|V| = 1M, |E| = 4M, F = 64): the hub pass beside the vertex panels on a second stream
 # (HG_TWO_STREAM=1) and a 512-thread hub workgroup that leaves half the register file to panel workgroups
-# (HG_HUB_THREADS=512).  Diagnostic build.  usage (GPU box): tools/pl_r04.sh > gpurun_out/pl_r04.log
+# (HG_HUB_THREADS=512).  Diagnostic build OF COMMIT 39c38fa: both switches lost and were removed from the tree afterwards
+# (profiles/r04_experiments.md, section 4).  usage (GPU box, that tree): tools/pl_r04.sh > gpurun_out/pl_r04.log
 root=$GRAFT_REPO_ROOT; [ -z "$root" ] && root=$(cd $(dirname $0)/.. && pwd)
 cd $root
 export HG_AGGR_LIB=$root/hypergef_amd/lib/libhgaggr_tuning.so
