@@ -1593,7 +1593,7 @@ static const Tuning &tuning() {
 #ifdef HG_TUNING
     if (const char *e = getenv("HG_UNROLL")) x.unroll = atoi(e) == 8 ? 8 : 4;
     if (const char *e = getenv("HG_PIPE")) x.pipe = atoi(e) != 0;
-    if (const char *e = getenv("HG_FUSED_U")) x.fused_u = atoi(e) == 16 ? 16 : 8;
+    if (const char *e = getenv("HG_FUSED_U")) x.fused_u = atoi(e) == 16 ? 16 : (atoi(e) == 12 ? 12 : (atoi(e) == 10 ? 10 : 8));
     if (const char *e = getenv("HG_FUSED_SMALL16")) x.fused_small16 = atoi(e) != 0;
     if (const char *e = getenv("HG_FUSED_FAST")) x.fused_fast = atoi(e) != 0;
     if (const char *e = getenv("HG_FUSED_COLTILE")) x.fused_coltile = atoi(e) != 0;
@@ -1869,6 +1869,14 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
       const bool u16 = t.fused_u == 16 || (t.fused_small16 && a.npanels <= 512);
       const int spec = (a.Xe_mat ? 1 : 0) | ((a.degE || a.W) ? 2 : 0);
 #define HG_PK(UU, M, S) return launch_lds<fused_packed_kernel<LPR, VEC, UU, true, M, S, false>>(grid, lds_p, stream, ad)
+#ifdef HG_TUNING
+      if (t.fused_u == 12 || t.fused_u == 10) {  // diagnostic build: ten / twelve gathers in flight (unweighted, weighted; no materialised slots)
+        if (spec == 0 && t.fused_u == 12) HG_PK(12, false, false);
+        if (spec == 2 && t.fused_u == 12) HG_PK(12, false, true);
+        if (spec == 0) HG_PK(10, false, false);
+        if (spec == 2) HG_PK(10, false, true);
+      }
+#endif
       if (u16) {
         switch (spec) {
           case 0: HG_PK(16, false, false);
