@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HG_AGGR_VERSION 300 /* major*10000 + minor*100 + patch */
+#define HG_AGGR_VERSION 400 /* round 4: + hg_aggr_linear_res_dev_f32 */
 
 #if defined(__GNUC__)
 #define HG_API __attribute__((visibility("default")))
