@@ -27,7 +27,7 @@ the oracle and against a float64 answer (scipy) at 1e-5 * max(1, |ref|).
 N > 1: one process per GPU (torchrun).  Headline: the batch sharded by hyperedge
 group = by hypergraph, K graphs per rank (weak scaling); no vertex is shared
 between shards, so the data path has no collective and ranks meet in the barrier
-that brackets the timed region.  `sharded` (beside it): ONE hypergraph (config 4)
+that brackets the timed region.  `strong_scaling` (beside it on the line; `sharded` in the detail file): ONE hypergraph (config 4)
 cut into hyperedge groups across the ranks by hypergef_amd.dist.ShardedAggregator
 -- X replicated, each rank aggregates its hyperedges into a dense partial, one
 RCCL all-reduce (or reduce-scatter) of N*F*4 bytes over xGMI sums them: the
