@@ -884,8 +884,8 @@ def main(argv=None):
     else:
         res, cpu, st = run_config(args.shape, args.replicas, F, args.weighted, args.variant, args.steps, args.warmup,
                                   dev, sync, barrier, rank, opts_kw,
-                                  want_cpu=one and not args.no_cpu_baseline, want_parity=one and not args.no_parity,
-                                  linear_out=args.linear_out)
+                                  want_cpu=one and not args.no_cpu_baseline, want_parity=not args.no_parity,
+                                  linear_out=args.linear_out)  # N > 1: rank 0 still checks its own shard's timed output
     wall = st["wall"]
     if world > 1:
         t = torch.tensor([wall], dtype=torch.float64, device=dev)
