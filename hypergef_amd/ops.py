@@ -361,12 +361,14 @@ class _AggrResLinear(torch.autograd.Function):
         gM = _wgrad(dP, T, opt.fuse_linear) if ctx.needs_input_grad[3] else None
         gx = None
         if ctx.needs_input_grad[2]:
-            g_in = dT * ca
+            g_in = dT if ca == 1.0 else dT * ca  # UniGIN: ca = 1 -- no [N, F] kernel for a multiplication by one
             if opt.backward == "reference" or degV is None:
                 gx = _SumAggrLinear._aggr(csrptr_t, indices_t, g_in, degE, degV, W, opt)
             else:
                 gx = _SumAggrLinear._aggr(csrptr_t, indices_t, g_in * degV.reshape(-1, 1), degE, None, W, opt)
-        gR = dT * cbf if (R is not None and ctx.needs_input_grad[4]) else None
+        gR = None
+        if R is not None and ctx.needs_input_grad[4]:
+            gR = dT if (not isinstance(cbf, torch.Tensor) and cbf == 1.0) else dT * cbf
         gcb = (dT * R).sum() if (R is not None and ctx.needs_input_grad[5]) else None
         return None, None, gx, gM, gR, gcb, None, None, None, None, None, None, None
 
