@@ -826,13 +826,33 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *A, const float 
 #pragma unroll
     for (int j = 0; j < TB; j++) acc[i][j] = hg_f4{0.f, 0.f, 0.f, 0.f};
   float a0[TA], b0[TB], a1[TA], b1[TB];
+  // Lane (kk, c) holds TA CONSECUTIVE floats of row n + kk -- columns TA c .. TA c + TA - 1, one 16-byte load at TA = 4 --
+  // and feeds the i-th of them to tile i: tile i then stands for the columns {TA c + i}, a permutation of the output's rows
+  // (columns for B) that the reduction below undoes.  Sixteen lanes read one whole 4 TA-float segment of a row per
+  // instruction; with tile i = columns 16 i .. 16 i + 15 (round 1) every row was fetched as TA separate 64-byte pieces.
   auto load = [&](int64_t n, float (&a)[TA], float (&b)[TB]) {
     const int64_t row = n + kk;
     const bool ok = row < r1;
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+    auto fetch = [&](const float *p, auto &dst, auto nt) {
+      constexpr int T = decltype(nt)::value;
+      if constexpr (T % 4 == 0) {
 #pragma unroll
-    for (int i = 0; i < TA; i++) a[i] = ok ? A[row * FA + i * 16 + c] : 0.f;
+        for (int q = 0; q < T / 4; q++) {
+          const f4u v = ok ? *reinterpret_cast<const f4u *>(p + 4 * q) : f4u{0.f, 0.f, 0.f, 0.f};
+          dst[4 * q] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
+        }
+      } else if constexpr (T == 2) {
+        const f2u v = ok ? *reinterpret_cast<const f2u *>(p) : f2u{0.f, 0.f};
+        dst[0] = v.x; dst[1] = v.y;
+      } else {
 #pragma unroll
-    for (int j = 0; j < TB; j++) b[j] = ok ? B[row * FB + j * 16 + c] : 0.f;
+        for (int q = 0; q < T; q++) dst[q] = ok ? p[q] : 0.f;
+      }
+    };
+    fetch(A + row * FA + c * TA, a, std::integral_constant<int, TA>{});
+    fetch(B + row * FB + c * TB, b, std::integral_constant<int, TB>{});
   };
   float a2[TA], b2[TB];
   if (r0 < r1) load(r0, a0, b0);
@@ -855,7 +875,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *A, const float 
       b1[j] = b2[j];
     }
   }
-  // D layout: register q of tile (i, j) is C[16 i + 4 (lane >> 4) + q][16 j + (lane & 15)]
+  // D layout: register q of tile (i, j) is tile row 4 (lane >> 4) + q, tile column lane & 15, i.e. (the load's permutation)
+  // C[TA (4 (lane >> 4) + q) + i][TB (lane & 15) + j]
   for (int w = 0; w < 4; w++) {
     if (wave == w) {
 #pragma unroll
@@ -864,7 +885,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *A, const float 
         for (int j = 0; j < TB; j++)
 #pragma unroll
           for (int q = 0; q < 4; q++) {
-            float *d = red + (i * 16 + 4 * kk + q) * FB + j * 16 + c;
+            float *d = red + (TA * (4 * kk + q) + i) * FB + TB * c + j;
             *d = w == 0 ? acc[i][j][q] : *d + acc[i][j][q];
           }
     }
