@@ -48,6 +48,7 @@ struct FusedArgs {
   int32_t max_rec_words;  // LDS space for one record
   int32_t ng;             // lane groups the records were packed for
   int32_t cap, rows_cap;  // LDS tile rows (hyperedge slots) and rows per panel
+  int32_t dv_regs = 0;    // set by the launcher: bound degV travels in registers, not through LDS (fused_packed_kernel)
   const float *X, *Xe_mat, *degE, *W, *degV;
   const float *bsA, *bsB, *bsD;  // bound scales in panel order (or null: gather from degE/W/degV)
   float *Y;

@@ -997,14 +997,30 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
 
   float *tile = reinterpret_cast<float *>(smem);        // [cap * TW]  (LIN: [cap * (TW + 4)])
   int32_t *rec = smem + a.cap * (LIN ? TW + 4 : TW);     // [max_rec_words], 16-byte aligned
-  // scale staging exists only for the scales this call has (the launcher sizes LDS the same way)
-  float *sA = reinterpret_cast<float *>(rec + a.max_rec_words);  // [cap]
-  float *sB = sA + a.cap;                                // [cap]
-  float *sdeg = (a.degE || a.W) ? sB + a.cap : sA;       // [rows_cap]
+  // scale staging exists only for the scales this call has (fused_scale_floats: the launcher sizes LDS the same way)
+  float *sA = reinterpret_cast<float *>(rec + a.max_rec_words);  // [cap], if degE
+  float *sB = sA + (a.degE ? a.cap : 0);                 // [cap], if W
+  float *sdeg = sB + (a.W ? a.cap : 0);                  // [rows_cap], if degV and not kept in registers (below)
 
   const FRec rt = a.rec_tab[b];
   HG_STAMP(0);
   const int32_t *grec = a.rec + rt.off;
+  const int g = tid / LPR;
+  // Bound degV, at most four rows per lane group, and the launcher found that the row factors' LDS costs a resident
+  // workgroup (a.dv_regs, fused_dv_regs): the lane group's four factors travel in registers from the start instead.  Those
+  // 512 bytes decide whether the weighted headline batch fits eight workgroups per CU or seven (20 112 against 20 624
+  // bytes per workgroup, 163 840 per CU).  SCALED instances only: the unweighted instance's code is untouched.
+  const bool dv_regs = SCALED && a.dv_regs != 0;
+  [[maybe_unused]] float dv[4] = {1.f, 1.f, 1.f, 1.f};
+  if constexpr (SCALED) {
+    if (dv_regs) {
+      const int rpg0 = (rt.nrows + NG - 1) / NG;
+      const int q0 = min(g * rpg0, rt.nrows), q1 = min(q0 + rpg0, rt.nrows);
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        if (q0 + i < q1) dv[i] = a.bsD[rt.row_base + q0 + i];
+    }
+  }
 
   // records are padded to whole 16-byte units: one dwordx4 per lane copies 4 KB per pass
   for (int i = tid; i < (rt.len >> 2); i += BS)
@@ -1019,11 +1035,11 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
         if (a.W) sB[i] = a.bsB[rt.slot_base + i];
       } else {
         const int e = a.eid_all[rt.slot_base + i];  // -1: materialised row, already scaled
-        sA[i] = (a.degE && e >= 0) ? a.degE[e] : 1.f;
-        sB[i] = (a.W && e >= 0) ? a.W[e] : 1.f;
+        if (a.degE) sA[i] = e >= 0 ? a.degE[e] : 1.f;
+        if (a.W) sB[i] = e >= 0 ? a.W[e] : 1.f;
       }
     }
-  if (a.degV)
+  if (a.degV && !dv_regs)
     for (int i = tid; i < rt.nrows; i += BS) {
       if (a.bsD) {
         sdeg[i] = a.bsD[rt.row_base + i];
@@ -1043,7 +1059,6 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
   const int32_t *prow = rec + rec[7];
   const uint16_t *pvs = reinterpret_cast<const uint16_t *>(rec + rec[9]);
 
-  const int g = tid / LPR;
   if (!(DBG && (a.debug & 4))) {  // ---- hop 1
     [[maybe_unused]] int slot = gbase[g];
     float *tp = tile + gbase[g] * TW + lcol;  // where this group's next finished slot goes
@@ -1170,7 +1185,7 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
       if (r < r1) {
         const int pb = r ? pend[r - 1] : 0, pe = pend[r];
         for (int p = pb; p < pe; p++) outr[i].add(V::load(tile + (int)pvs[p] * TW + lcol));
-        if (a.degV && pe > pb) outr[i].mul(sdeg[r]);
+        if (a.degV && pe > pb) outr[i].mul(dv_regs ? dv[i] : sdeg[r]);
       }
     }
     if (a.epi.R || a.epi.ca != 1.f) {  // t' = ca * t + cb * R[v]  (workgroup-uniform)
@@ -1218,11 +1233,11 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
   } else if (!(DBG && (a.debug & 8))) {  // ---- hop 2
     const int rpg = (nrows + NG - 1) / NG;
     const int r0 = min(g * rpg, nrows), r1 = min(r0 + rpg, nrows);
-    for (int r = r0; r < r1; r++) {
+    auto row = [&](const int r, const float dscale) {  // dscale: the row's degV where it came in a register, else read from LDS
       V acc = V::zero();
       const int pb = r ? pend[r - 1] : 0, pe = pend[r];
       for (int p = pb; p < pe; p++) acc.add(V::load(tile + (int)pvs[p] * TW + lcol));
-      if (a.degV && pe > pb) acc.mul(sdeg[r]);
+      if (a.degV && pe > pb) acc.mul(dv_regs ? dscale : sdeg[r]);
       if (col_ok && !(DBG && (a.debug & 2))) {
         const int pr = prow[r];  // vertex id, or bit 31 | partial row (a piece of a split vertex)
         float *dst = (pr < 0 ? a.partial + (int64_t)(pr & 0x7fffffff) * F : a.Y + (int64_t)pr * F) + col;
@@ -1230,6 +1245,13 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
         else if (HG_Y_NT && a.y_nt && pr >= 0) acc.store_n_nt(dst, a.F - col);  // partial rows are read back by the fixup pass: plain
         else acc.store_n(dst, a.F - col);
       }
+    };
+    if (SCALED && dv_regs) {  // at most four rows, their factors in dv[0..3] (static indices)
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        if (r0 + i < r1) row(r0 + i, dv[i]);
+    } else {
+      for (int r = r0; r < r1; r++) row(r, 1.f);
     }
   }
   HG_STAMP(5);
@@ -1824,6 +1846,24 @@ hipError_t launch_hub_pass(const HubArgs &a0, bool vec4, hipStream_t stream) {
   return hipErrorInvalidValue;
 }
 
+// floats of LDS the panel kernel stages scales in (its sA / sB / sdeg carve-up): degE and W per slot where present, degV per
+// row unless it travels in registers (a.dv_regs)
+static size_t fused_scale_floats(const FusedArgs &a) {
+  return (size_t)(a.degE ? a.cap : 0) + (size_t)(a.W ? a.cap : 0) + (size_t)((a.degV && !a.dv_regs) ? a.rows_cap : 0);
+}
+// Bound degV in registers (fused_packed_kernel) where it can be (SCALED instance, at most four rows per lane group) AND its
+// LDS would cost a resident workgroup: measured on one box, weighted batches at F = 32: cora x1024 0.597-0.600 -> 0.611-0.614
+// of the roofline, citeseer 0.680 -> 0.690, pubmed x256 0.459 -> 0.497 (seven -> eight workgroups per CU); at F = 128, where
+// eight fit either way, the register form costs 4.5 % (cora x256 0.589 -> 0.562) and is not used.
+static int fused_dv_regs(const FusedArgs &a, int ng, size_t lds_without_scales, int max_wgs) {
+  if (!((a.degE || a.W) && a.degV && a.bsD && a.rows_cap <= 4 * ng)) return 0;
+  const size_t common = lds_without_scales + ((size_t)(a.degE ? a.cap : 0) + (size_t)(a.W ? a.cap : 0)) * 4;
+  const size_t with = common + (size_t)a.rows_cap * 4;
+  const int fit_with = (int)std::min<size_t>((size_t)max_wgs, kLdsMax / with);
+  const int fit_without = (int)std::min<size_t>((size_t)max_wgs, kLdsMax / common);
+  return fit_without > fit_with ? 1 : 0;
+}
+
 template <int LPR, int VEC>
 static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
   if (a.npanels == 0) return hipSuccess;
@@ -1834,8 +1874,7 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
       const bool fast = a.x_bytes > 0 && a.nrows_x < (1 << 24) && a.F < (1 << 22) && (a.F & 3) == 0;
       if (!fast || a.Wlin || a.Xe_mat) return hipErrorInvalidValue;
       const dim3 grid(a.npanels, (a.F + TW - 1) / TW);
-      const size_t lds = (size_t)a.cap * TW * 4 + (size_t)a.max_rec_words * 4 +
-                         (size_t)(((a.degE || a.W) ? 2 * a.cap : 0) + (a.degV ? a.rows_cap : 0)) * 4 + 16;
+      const size_t lds = (size_t)a.cap * TW * 4 + (size_t)a.max_rec_words * 4 + fused_scale_floats(a) * 4 + 16;  // dv_regs = 0
       if (a.degE || a.W) return launch_lds<fused_packed_kernel<LPR, VEC, 8, true, false, true, false, false, 1024>, 1024>(grid, lds, stream, a);
       return launch_lds<fused_packed_kernel<LPR, VEC, 8, true, false, false, false, false, 1024>, 1024>(grid, lds, stream, a);
     }
@@ -1848,8 +1887,9 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
   const dim3 grid(a.npanels, col_tiles);
   // tile | record | scale staging (only what this call's scales need: without them the F = 32
   // bench shape fits 8 workgroups per CU instead of 7)
-  const size_t lds_p = (size_t)a.cap * TW * 4 + (size_t)a.max_rec_words * 4 +
-                       (size_t)(((a.degE || a.W) ? 2 * a.cap : 0) + (a.degV ? a.rows_cap : 0)) * 4 + 16;
+  // (the linear epilogue's instances stage degV in LDS: their tile already decides the residency)
+  ad.dv_regs = a.Wlin ? 0 : fused_dv_regs(a, 256 / LPR, (size_t)a.cap * TW * 4 + (size_t)a.max_rec_words * 4 + 16, 8);
+  const size_t lds_p = (size_t)a.cap * TW * 4 + (size_t)a.max_rec_words * 4 + fused_scale_floats(ad) * 4 + 16;
   if constexpr (VEC == 4) {
     const bool fast = t.fused_fast && a.x_bytes > 0 && a.nrows_x < (1 << 24) && a.F < (1 << 22) &&
                       (!a.Xe_mat || (a.mat_bytes > 0 && a.nrows_mat < (1 << 24)));
