@@ -179,8 +179,11 @@ double small_graph_cost(const hg::FusedSched &f) {
 // the slots do (pubmed-shape, F = 128: 32 slots hold 24 rows on average; 48 hold the 32).  lin_caps() returns false
 // where the default schedule is already that shape (F = 32: 128 rows of 128 slots) or the caller fixed the tile.
 bool lin_caps(const hg_plan *p, int32_t F, bool vec4, int32_t &cap, int32_t &mem_cap, int32_t &rows_cap) {
-  // F = 128 only: at F = 64 the default panels hold 53 of their 64 rows already, and every larger tile lost there
-  // (cora x1024 64 -> 64: 0.463 ms default, 0.469-0.475 with 80 slots, 0.485-0.492 with 96; profiles/r04_experiments.md)
+  // F = 128 only.  At F = 64 the default panels hold 53 of their 64 rows already, and every larger tile lost there (cora
+  // x1024 64 -> 64: 0.463 ms default, 0.469-0.475 with 80 slots, 0.485-0.492 with 96).  At F = 32 a cap of 112 rows (seven
+  // tiles) lets the operand rows fit the slot tile's 16 KB -- 19 600 instead of 21 648 bytes of LDS, eight resident
+  // workgroups instead of seven -- and changed nothing: 32 -> 32 0.209-0.213 ms either way, 32 -> 64 -1 % (9 % more panels
+  // eat the eighth workgroup; profiles/r04_experiments.md).
   if (!vec4 || F != 128 || !p->opts.fused_tile_auto || p->opts.fused_steps > 0 || p->nnz <= (1 << 18)) return false;
   int pct = 150;
 #ifdef HG_TUNING

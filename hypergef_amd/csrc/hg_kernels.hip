@@ -949,6 +949,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *partial,
 typedef unsigned hg_u4 __attribute__((ext_vector_type(4)));
 typedef int hg_i4 __attribute__((ext_vector_type(4)));
 
+// Floats of the linear epilogue's tile region: cap slot rows of tw floats in hops 1 and 2, then the operand rows of the
+// matrix phase (the panel's rows, whole 16-row tiles, stride tw + 4).  A multiple of four floats (16-byte aligned record).
+__host__ __device__ inline int lin_tile_floats(int cap, int rows_cap, int tw) {
+  const int rows16 = (rows_cap + 15) / 16 * 16;
+  const int a = cap * tw, b = rows16 * (tw + 4);
+  return a > b ? a : b;
+}
+
 // FAST: rows are fetched with buffer_load_dwordx4 (VEC = 1: buffer_load_dword) through a buffer
 // descriptor and a 32-bit byte offset formed by one v_mad_u32_u24 (row * row_bytes +
 // column bytes) instead of 64-bit pointer arithmetic; needs N < 2^24, F*4 < 2^24 and
@@ -995,8 +1003,10 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
   }
   HG_STAMP_INIT(true);
 
-  float *tile = reinterpret_cast<float *>(smem);        // [cap * TW]  (LIN: [cap * (TW + 4)])
-  int32_t *rec = smem + a.cap * (LIN ? TW + 4 : TW);     // [max_rec_words], 16-byte aligned
+  // [cap * TW] slot rows; LIN: the same floats later hold the matrix phase's operand, [rows_cap up to whole 16-row tiles]
+  // rows of TW + 4 floats -- the region is the larger of the two (lin_tile_floats: the launcher sizes it the same way)
+  float *tile = reinterpret_cast<float *>(smem);
+  int32_t *rec = smem + (LIN ? lin_tile_floats(a.cap, a.rows_cap, TW) : a.cap * TW);  // [max_rec_words], 16-byte aligned
   // scale staging exists only for the scales this call has (fused_scale_floats: the launcher sizes LDS the same way)
   float *sA = reinterpret_cast<float *>(rec + a.max_rec_words);  // [cap], if degE
   float *sB = sA + (a.degE ? a.cap : 0);                 // [cap], if W
@@ -1896,7 +1906,7 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
     if (a.Wlin) {  // linear epilogue: eligibility was checked by fused_linear_ok
       if constexpr (TW == 32 || TW == 64 || TW == 128) {
         if (!fast || a.F != TW || a.rows_cap > 4 * (256 / LPR) || (a.F_out & 15)) return hipErrorInvalidValue;
-        const size_t lds_l = lds_p + (size_t)a.cap * 4 * 4;  // + 4 pad floats per tile row
+        const size_t lds_l = lds_p - (size_t)a.cap * TW * 4 + (size_t)lin_tile_floats(a.cap, a.rows_cap, TW) * 4;  // slot tile / padded operand rows
         const int spec = (a.Xe_mat ? 1 : 0) | ((a.degE || a.W) ? 2 : 0);
         // the staged matrix phase alone serves this call (as panel_times_wt decides per panel, for the fullest panel)
         const int nt_all = a.F_out >> 4, nwr = nt_all >= 3 ? 1 : 4 / nt_all;
