@@ -357,19 +357,24 @@ class _AggrResLinear(torch.autograd.Function):
         if relu:
             dP = torch.ops.aten.threshold_backward(dP, out, 0.0)  # relu's own backward: one vectorised kernel
         opt = ctx.opt
-        dT = _rows_times(dP, M, opt.fuse_linear)
+        need_gcb = R is not None and ctx.needs_input_grad[5]
+        # dX wants ca * (dP . M): the factor rides in the [F_out, F_in] matrix (one tiny kernel) instead of an [N, F] pass over
+        # the product, unless the unscaled product is needed for d cb (UniGIN, where ca = 1 anyway)
+        fold = ca != 1.0 and not need_gcb
+        dT = _rows_times(dP, M * ca if fold else M, opt.fuse_linear)
         gM = _wgrad(dP, T, opt.fuse_linear) if ctx.needs_input_grad[3] else None
         gx = None
         if ctx.needs_input_grad[2]:
-            g_in = dT if ca == 1.0 else dT * ca  # UniGIN: ca = 1 -- no [N, F] kernel for a multiplication by one
+            g_in = dT if (fold or ca == 1.0) else dT * ca  # UniGIN: ca = 1 -- no [N, F] kernel for a multiplication by one
             if opt.backward == "reference" or degV is None:
                 gx = _SumAggrLinear._aggr(csrptr_t, indices_t, g_in, degE, degV, W, opt)
             else:
                 gx = _SumAggrLinear._aggr(csrptr_t, indices_t, g_in * degV.reshape(-1, 1), degE, None, W, opt)
         gR = None
         if R is not None and ctx.needs_input_grad[4]:
-            gR = dT if (not isinstance(cbf, torch.Tensor) and cbf == 1.0) else dT * cbf
-        gcb = (dT * R).sum() if (R is not None and ctx.needs_input_grad[5]) else None
+            cbr = cbf / ca if fold else cbf  # dT already carries ca
+            gR = dT if (not isinstance(cbr, torch.Tensor) and cbr == 1.0) else dT * cbr
+        gcb = (dT * R).sum() if need_gcb else None
         return None, None, gx, gM, gR, gcb, None, None, None, None, None, None, None
 
 
