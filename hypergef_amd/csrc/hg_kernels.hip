@@ -939,6 +939,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *partial,
 #ifndef HG_LIN_WAVES_STAGED32
 #define HG_LIN_WAVES_STAGED32 6
 #endif
+#ifndef HG_MERGE_PHASES_PLAIN
+#define HG_MERGE_PHASES_PLAIN 1  // the plain panels with materialised slots too: both hop-1 phases in one run of batches of eight (same box,
+                                 // three rounds: pubmed x256 F = 32 0.512-0.515 -> 0.526-0.529 of the roofline, x64 F = 128 0.502-0.503 -> 0.507-0.510,
+                                 // weighted pubmed 0.494-0.496 -> 0.505-0.510, power-law step 0.917-0.921 -> 0.907-0.912 ms)
+#endif
 #ifndef HG_LIN_MERGE_PHASES
 #define HG_LIN_MERGE_PHASES 1  // K = 128 staged epilogue instances: hop 1's two phases as one run of batches (with twelve gathers in
                                // flight at the six-wave budget: -1.2 % on pubmed x64 128 -> 128, -2.2 % on 128 -> 64, same box, three rounds)
@@ -1129,10 +1134,11 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
       }
     };
     const int steps_x = MAT ? rec[8] : steps;
-    if constexpr (MAT && FAST && HG_LIN_MERGE_PHASES && LIN && !LINW && LPR >= 32) {
+    if constexpr (MAT && FAST && ((HG_LIN_MERGE_PHASES && LIN && !LINW && LPR >= 32) || (HG_MERGE_PHASES_PLAIN && !LIN && VEC == 4 && BS == 256))) {
       // Both phases in ONE run of batches, the descriptor picked per step (wave-uniform): a pubmed-shape panel of the
       // epilogue's schedule has ~7 steps of X rows and ~4 of materialised rows -- two dependent round trips as two
-      // phases, one as a batch of twelve.
+      // phases, one as a batch of twelve.  The plain panels with materialised slots run it with batches of eight: a
+      // panel's last X batch and its materialised rows share a round trip.
       auto mixed = [&](const int s0, auto full) {
         constexpr bool FULL = decltype(full)::value;
         int ent[U];
