@@ -31,7 +31,7 @@ SYMBOLS = (
     "hg_plan_create_host", "hg_plan_create_device", "hg_plan_destroy", "hg_plan_get_info",
     "hg_plan_get_vertex_csr", "hg_plan_get_vertex_csr_device", "hg_plan_get_schedule", "hg_plan_prepare", "hg_plan_auto_variant", "hg_plan_bind_scales", "hg_plan_tune_f32",
     "hg_plan_workspace_bytes",
-    "hg_aggr_fused_f32", "hg_linear_pack_f32", "hg_linear_rows_f32", "hg_linear_wgrad_workspace_bytes", "hg_linear_wgrad_f32", "hg_aggr_linear_workspace_bytes", "hg_aggr_linear_f32", "hg_aggr_linear_res_f32", "hg_aggr_linear_res_dev_f32",
+    "hg_aggr_fused_f32", "hg_linear_pack_f32", "hg_linear_pack_ex_f32", "hg_linear_pack_floats", "hg_linear_rows_f32", "hg_linear_wgrad_workspace_bytes", "hg_linear_wgrad_f32", "hg_aggr_linear_workspace_bytes", "hg_aggr_linear_f32", "hg_aggr_linear_res_f32", "hg_aggr_linear_res_dev_f32",
     "hg_gather_rows_f32", "hg_aggr_push_groups_f32", "hg_gather_max_f32",
     "hg_scatter_record_f32",
 )
@@ -135,6 +135,10 @@ def lib():
     L.hg_plan_tune_f32.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, sz, i32, vp, ctypes.POINTER(TuneInfo)]
     L.hg_linear_pack_f32.restype = ctypes.c_int
     L.hg_linear_pack_f32.argtypes = [i32, i32, vp, vp, vp]
+    L.hg_linear_pack_ex_f32.restype = ctypes.c_int
+    L.hg_linear_pack_ex_f32.argtypes = [i32, i32, vp, vp, i32, vp]
+    L.hg_linear_pack_floats.restype = sz
+    L.hg_linear_pack_floats.argtypes = [i32, i32, i32]
     L.hg_linear_wgrad_workspace_bytes.restype = sz
     L.hg_linear_wgrad_workspace_bytes.argtypes = [i64, i32, i32]
     L.hg_linear_wgrad_f32.restype = ctypes.c_int

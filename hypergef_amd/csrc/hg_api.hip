@@ -1321,6 +1321,20 @@ int hg_linear_pack_f32(int32_t F_out, int32_t F_in, const float *Wlin, float *wf
   return HG_OK;
 }
 
+size_t hg_linear_pack_floats(int32_t F_out, int32_t F_in, int32_t flags) {
+  if (F_out <= 0 || F_in <= 0) return 0;
+  const size_t n = (size_t)F_out * F_in;
+  return ((flags & HG_LIN_BF16X6) && F_in == 128) ? n + n * 3 / 2 : n;  // + three bf16 planes
+}
+
+int hg_linear_pack_ex_f32(int32_t F_out, int32_t F_in, const float *Wlin, float *wfrag, int32_t flags, hg_stream_t stream) {
+  int rc = hg_linear_pack_f32(F_out, F_in, Wlin, wfrag, stream);
+  if (rc != HG_OK || !(flags & HG_LIN_BF16X6) || F_in != 128) return rc;
+  hipError_t e = hg::launch_linear_pack_split(F_out, F_in, Wlin, wfrag + (size_t)F_out * F_in, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return hip_fail("linear_pack_split launch", e);
+  return HG_OK;
+}
+
 int hg_linear_rows_f32(int64_t nrows, int32_t F_in, int32_t F_out, const float *T, const float *wfrag, float *Y,
                        hg_stream_t stream) {
   if (nrows < 0 || !wfrag || (nrows > 0 && (!T || !Y))) {
@@ -1420,7 +1434,8 @@ static int aggr_linear_res(const hg_plan *plan, int32_t F_in, int32_t F_out, con
   lin.epi.ca = ca;
   lin.epi.cb = R ? cb : 0.f;
   lin.epi.cb_dev = R ? cb_dev : nullptr;
-  lin.epi.relu = relu ? 1 : 0;
+  lin.epi.relu = (relu & HG_LIN_RELU) ? 1 : 0;
+  lin.epi.wsplit = ((relu & HG_LIN_BF16X6) && F_in == 128) ? wfrag + (size_t)F_out * F_in : nullptr;
   lin.epi.T_out = T_out;
   int rc = aggr_impl(plan, F_in, csrptr_t, colind_t, X, degE, degV, W, T, workspace, base, variant, stream, &lin);
   if (rc != HG_OK || lin.done) return rc;

@@ -38,6 +38,8 @@ struct LinEpilogue {
   const float *cb_dev = nullptr;  // non-null: cb is this device scalar, read when the kernel runs (a learned 1 + eps)
   int32_t relu = 0;
   float *T_out = nullptr;
+  const void *wsplit = nullptr;  // Wlin as three bf16 planes in fragment order (launch_linear_pack_split): the fused panels' K = 128
+                                 // matrix phase may then run as six bf16 products per fp32 product (HG_LIN_BF16X6)
 };
 
 struct FusedArgs {
@@ -134,6 +136,7 @@ int wgrad_parts(int64_t nrows, int32_t Fa, int32_t Fb);
 hipError_t launch_wgrad(int64_t nrows, int32_t Fa, int32_t Fb, const float *A, const float *B, float *C,
                         float *partial, hipStream_t stream);
 hipError_t launch_linear_pack(int32_t F_out, int32_t F_in, const float *Wlin, float *wfrag, hipStream_t stream);
+hipError_t launch_linear_pack_split(int32_t F_out, int32_t F_in, const float *Wlin, void *wsplit, hipStream_t stream);
 int fused_tile_row_floats(int F, bool vec4);
 hipError_t read_stamps(unsigned long long *out, bool reset);
 hipError_t launch_mfma_rate(int blocks, int iters, float *sink, unsigned long long *ticks, hipStream_t stream);

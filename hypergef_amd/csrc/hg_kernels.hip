@@ -671,6 +671,181 @@ __device__ __forceinline__ void panel_times_wt_staged_chunked(float *t, int nrow
   HG_STAMP(11);
 }
 
+// ---- fp32 by six bf16 products (K = 128 staged epilogue, HG_LIN_BF16X6) ---------------------------------------------
+// v_mfma_f32_16x16x4_f32 moves 64 FLOP per clock and SIMD, v_mfma_f32_16x16x32_bf16 1024.  A float is the sum of three
+// bf16 numbers up to 2^-24 of itself (h = rn(x), m = rn(x - h), l = rn(x - h - m): both differences are exact), a product
+// of two bf16 numbers is exact in fp32 and the matrix pipe accumulates in fp32, so
+//   a * b = ah bh + (ah bm + am bh) + (ah bl + al bh + am bm) + O(2^-23 |a b|)
+// -- six MFMAs of the bf16 form for what eight of the fp32 form do, at a sixteenth of the cycles each (16 against 32 per
+// instruction, K = 32 against 4): the matrix phase's pipe time falls to 3/8.  The dropped terms (am bl, al bm, al bl and the
+// split's own residual) are below one rounding of the fp32 product; the sum over k is fp32 either way.  What changes is the
+// ORDER of the additions (the pipe adds 32 products per instruction, and the six partial products per k land apart), so
+// results differ from the fp32 form in the last bits, as any fp32 GEMM's do from another's: tests bound both forms by the
+// same 1e-5 x row mass against float64.  (The scheme TPUs call bf16_6x / "highest" precision.)
+// Operand rows: three planes of [32 rows][128] bf16 in the tile region (24 KB = the 48 slot rows of the epilogue's
+// schedule), 16-byte chunk c of row r stored at chunk c ^ (r & 15): the A-fragment read (ds_read_b128, lane l = row l & 15,
+// k-block l >> 4) and the 8-byte writes of hop 2's lanes both touch every bank once per 16 lanes.
+typedef __bf16 hg_bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 hg_bf2 __attribute__((ext_vector_type(2)));
+typedef float hg_f2 __attribute__((ext_vector_type(2)));
+constexpr int kSplitPlaneBytes = 32 * 256;
+
+__device__ __forceinline__ void split_bf16x3(float x, float y, unsigned &h, unsigned &m, unsigned &l) {
+  const hg_f2 v{x, y};
+  const hg_bf2 hb = __builtin_convertvector(v, hg_bf2);  // v_cvt_pk_bf16_f32: round to nearest even
+  const hg_f2 r1 = v - __builtin_convertvector(hb, hg_f2);
+  const hg_bf2 mb = __builtin_convertvector(r1, hg_bf2);
+  const hg_f2 r2 = r1 - __builtin_convertvector(mb, hg_f2);
+  const hg_bf2 lb = __builtin_convertvector(r2, hg_bf2);
+  h = __builtin_bit_cast(unsigned, hb);
+  m = __builtin_bit_cast(unsigned, mb);
+  l = __builtin_bit_cast(unsigned, lb);
+}
+// byte offset inside a plane of the 8 bytes that hold columns k .. k + 3 of row r (k a multiple of 4)
+__device__ __forceinline__ int split_off(int r, int k) { return r * 256 + ((((k >> 3) ^ r) & 15) << 4) + ((k & 4) << 1); }
+
+__device__ __forceinline__ void split_store_row(char *planes, int r, int k, const float4 &v) {
+  unsigned h0, m0, l0, h1, m1, l1;
+  split_bf16x3(v.x, v.y, h0, m0, l0);
+  split_bf16x3(v.z, v.w, h1, m1, l1);
+  char *p = planes + split_off(r, k);
+  *reinterpret_cast<uint2 *>(p) = make_uint2(h0, h1);
+  *reinterpret_cast<uint2 *>(p + kSplitPlaneBytes) = make_uint2(m0, m1);
+  *reinterpret_cast<uint2 *>(p + 2 * kSplitPlaneBytes) = make_uint2(l0, l1);
+}
+
+// Wlin's three planes in fragment order, behind the fp32 fragments of linear_pack_kernel (hub rows and the other
+// variants' rows still go through linear_rows_kernel):
+//   wsplit[(((nt * K/32 + ks) * 3 + p) * 64 + lane)] = 8 bf16: plane p of Wlin[nt*16 + (lane & 15)][ks*32 + 8*(lane >> 4) + j]
+__global__ __launch_bounds__(256) void linear_pack_split_kernel(int32_t F_out, int32_t F_in, const float *Wlin, uint4 *wsplit) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (nt, ks, lane)
+  const int k32 = F_in >> 5;
+  if (i >= (int64_t)(F_out >> 4) * k32 * 64) return;
+  const int lane = (int)(i & 63), ks = (int)((i >> 6) % k32), nt = (int)((i >> 6) / k32);
+  const float *w = Wlin + (int64_t)(nt * 16 + (lane & 15)) * F_in + ks * 32 + 8 * (lane >> 4);
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) split_bf16x3(w[2 * j], w[2 * j + 1], h[j], m[j], l[j]);
+  uint4 *o = wsplit + ((int64_t)(nt * k32 + ks) * 3) * 64 + lane;
+  o[0] = make_uint4(h[0], h[1], h[2], h[3]);
+  o[64] = make_uint4(m[0], m[1], m[2], m[3]);
+  o[128] = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+struct SplitB {
+  uint4 h, m, l;
+};
+__device__ __forceinline__ SplitB load_bsplit(const uint4 *wsplit, int nt, int ks, int lane) {
+  const uint4 *w = wsplit + ((int64_t)(nt * 4 + ks) * 3) * 64 + lane;
+  return SplitB{w[0], w[64], w[128]};
+}
+__device__ __forceinline__ hg_f4 mfma_bf16(const uint4 &a, const uint4 &b, hg_f4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(hg_bf8, a), __builtin_bit_cast(hg_bf8, b), c, 0, 0, 0);
+}
+
+// NRT row tiles against the wave's NPW column tiles, K = 128 = four steps of 32, (step, column tile) by (step, column
+// tile): the B fragments of the next one (three dwordx4 from the L2) are in flight during this one's 6 * NRT MFMAs; a row
+// tile's A fragments (three ds_read_b128) are read per column tile -- held across both they would be 24 more registers
+// than the six-wave budget has.  The small products go in first.
+template <int NPW, int NRT>
+__device__ __forceinline__ void mfma_rows_split(const char *planes, const uint4 *wsplit, const LinSplit &sp, int NT, int lane,
+                                                const SplitB &bpre, hg_f4 *acc) {
+  constexpr int RPN = 4 / NPW;
+  int nvalid = 0;  // column tiles this wave really has (wave-uniform)
+#pragma unroll
+  for (int ni = 0; ni < NPW; ni++) nvalid += (sp.nt_first + ni * sp.nt_step < NT) ? 1 : 0;
+  SplitB bcur = bpre, bnxt = bpre;
+  const int r = lane & 15, kb = lane >> 4;
+  const char *prow = planes + (sp.rt_first * 16 + r) * 256;
+  const int rstep = sp.rt_step * 16 * 256;
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) {
+    const int coff = (((ks * 4 + kb) ^ r) & 15) << 4;
+#pragma unroll
+    for (int ni = 0; ni < NPW; ni++) {
+      if (ni < nvalid) {
+        const int ni2 = ni + 1 < nvalid ? ni + 1 : 0, ks2 = ni + 1 < nvalid ? ks : ks + 1;  // this wave's next (column tile, step)
+        if (ks2 < 4) bnxt = load_bsplit(wsplit, sp.nt_first + ni2 * sp.nt_step, ks2, lane);
+#pragma unroll
+        for (int j = 0; j < NRT; j++) {
+          const char *p = prow + j * rstep + coff;
+          const uint4 ah = *reinterpret_cast<const uint4 *>(p);
+          const uint4 am = *reinterpret_cast<const uint4 *>(p + kSplitPlaneBytes);
+          const uint4 al = *reinterpret_cast<const uint4 *>(p + 2 * kSplitPlaneBytes);
+          hg_f4 c = acc[ni * RPN + j];
+          c = mfma_bf16(al, bcur.h, c);
+          c = mfma_bf16(ah, bcur.l, c);
+          c = mfma_bf16(am, bcur.m, c);
+          c = mfma_bf16(am, bcur.h, c);
+          c = mfma_bf16(ah, bcur.m, c);
+          c = mfma_bf16(ah, bcur.h, c);
+          acc[ni * RPN + j] = c;
+        }
+        bcur = bnxt;
+      }
+    }
+  }
+}
+
+// panel_times_wt_staged_chunked on the split operands: planes = the tile region (operand rows as three bf16 planes); the
+// fp32 results go back into the same region as [rows][K + 4] floats and leave as whole rows.
+template <int NPW>
+__device__ __forceinline__ void panel_times_wt_split(float *t, int nrows, int F_out, const uint4 *wsplit, const int32_t *rowmap,
+                                                     float *Y, int tid, const SplitB &bpre, int relu, Stamper &stp) {
+  constexpr int K = 128, LD = K + 4, RPN = 4 / NPW;
+  const int lane = tid & 63;
+  const int NT = F_out >> 4, RT = (nrows + 15) >> 4;
+  const LinSplit sp = lin_split(tid >> 6, NT);
+  hg_f4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) acc[j] = hg_f4{0.f, 0.f, 0.f, 0.f};
+  int nrt = 0;
+  if (sp.active) {
+    nrt = min(2, max(0, (RT - sp.rt_first + sp.rt_step - 1) / sp.rt_step));  // at most 32 rows (launcher)
+    const char *planes = reinterpret_cast<const char *>(t);
+    if constexpr (NPW == 2) {
+      // F_out > 64: every wave walks the row tiles from 0 (lin_split) -- both tiles always, no branch around the preloaded
+      // fragments (a panel of the epilogue's schedule has 29 of its 32 rows on average; the second tile of a shorter one
+      // multiplies whatever the planes hold there, and those rows are never stored)
+      nrt = RT;
+      mfma_rows_split<NPW, 2>(planes, wsplit, sp, NT, lane, bpre, acc);
+    } else if (nrt == 2) {
+      mfma_rows_split<NPW, 2>(planes, wsplit, sp, NT, lane, bpre, acc);
+    } else if (nrt == 1) {
+      mfma_rows_split<NPW, 1>(planes, wsplit, sp, NT, lane, bpre, acc);
+    }
+  }
+  HG_STAMP(8);
+  __syncthreads();  // every wave has read its A fragments: the planes can be overwritten
+  HG_STAMP(9);
+  if (sp.active) {
+#pragma unroll
+    for (int ni = 0; ni < NPW; ni++) {
+      const int nt = sp.nt_first + ni * sp.nt_step;
+      if (nt < NT) {
+#pragma unroll
+        for (int j = 0; j < RPN; j++)
+          if (j < nrt) {
+            float *d = t + ((sp.rt_first + j * sp.rt_step) * 16 + 4 * (lane >> 4)) * LD + nt * 16 + (lane & 15);
+#pragma unroll
+            for (int i = 0; i < 4; i++) d[i * LD] = acc[ni * RPN + j][i];
+          }
+      }
+    }
+  }
+  __syncthreads();
+  HG_STAMP(10);
+  const int q = F_out >> 2;  // float4 pieces per row
+  for (int i = tid; i < nrows * q; i += 256) {
+    const int r = i / q, c = (i - r * q) * 4;
+    float4 o = *reinterpret_cast<const float4 *>(t + r * LD + c);
+    if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+    if (HG_Y_NT) Vec<4>{o}.store_nt(Y + (int64_t)rowmap[r] * F_out + c);
+    else *reinterpret_cast<float4 *>(Y + (int64_t)rowmap[r] * F_out + c) = o;
+  }
+  HG_STAMP(11);
+}
+
 // WIDE = false: the caller guarantees the staged form applies (F_out <= K and few enough row tiles); the direct form
 // for wider outputs is then not compiled in -- its registers would set the budget of the whole kernel.
 template <int KSTEPS, bool WIDE = true>
@@ -980,9 +1155,11 @@ __host__ __device__ inline int lin_tile_floats(int cap, int rows_cap, int tw) {
 // takes -- the direct form is compiled in.  LINW = false instances (F_out <= F, the common case) carry the staged form
 // only and fit 8 waves per SIMD without spills; the direct form's registers used to set the budget of every LIN
 // instance (natural demand 85-92 VGPRs, 5-6 waves).
-template <int LPR, int VEC, int U, bool FAST, bool MAT, bool SCALED, bool DBG, bool LIN = false, int BS = 256, bool LINW = true>
+// SPLIT (LIN, !LINW, K = 128 only): the matrix phase as six bf16 products per fp32 product (mfma_rows_split); a.epi.wsplit.
+template <int LPR, int VEC, int U, bool FAST, bool MAT, bool SCALED, bool DBG, bool LIN = false, int BS = 256, bool LINW = true, bool SPLIT = false>
 __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW ? (LPR >= 32 ? HG_LIN_WAVES_STAGED32 : HG_LIN_WAVES_STAGED) : LPR >= 32 ? HG_LIN_WAVES32 : LPR == 16 ? HG_LIN_WAVES16 : HG_LIN_WAVES8) : 1, 8))) void fused_packed_kernel(const FusedArgs a) {
   static_assert(!LIN || BS == 256, "the linear epilogue is written for four waves");
+  static_assert(!SPLIT || (LIN && !LINW && LPR == 32 && VEC == 4), "bf16x6 matrix phase: K = 128 staged instances");
   constexpr int NG = BS / LPR;
   constexpr int TW = LPR * VEC;
   using V = Vec<VEC>;
@@ -1189,7 +1366,8 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
   if constexpr (LIN) {  // ---- hop 2 into registers, then rows * Wlin^T on the matrix cores
     // the B fragments of this wave's first column tile are issued after hop 2 and fly across the two barriers that
     // follow (issued before hop 2 they would hold K/4 more registers through it: 78 instead of 64 VGPRs)
-    float bv[BPre<TW / 4>::N];
+    [[maybe_unused]] float bv[BPre<TW / 4>::N];
+    [[maybe_unused]] SplitB bsp;
     const LinSplit sp = lin_split(tid >> 6, a.F_out >> 4);
     const int rpg = (nrows + NG - 1) / NG;  // <= 4 (launcher)
     const int r0 = min(g * rpg, nrows), r1 = min(r0 + rpg, nrows);
@@ -1216,6 +1394,26 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
             outr[i].add(rr);
           }
         }
+    }
+    if constexpr (SPLIT) {
+      if (sp.active) bsp = load_bsplit(static_cast<const uint4 *>(a.epi.wsplit), sp.nt_first, 0, tid & 63);
+      if (a.epi.T_out) {  // the combined rows themselves, for the backward pass: straight from the registers
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if (r0 + i < r1) outr[i].store(a.epi.T_out + (int64_t)prow[r0 + i] * TW + lcol);
+      }
+      HG_STAMP(5);
+      __syncthreads();  // every slot row has been read: the tile becomes the operand's three bf16 planes
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        if (r0 + i < r1) split_store_row(reinterpret_cast<char *>(tile), r0 + i, lcol, outr[i].v);
+      __syncthreads();
+      HG_STAMP(6);
+      HG_STAMP(7);
+      if (a.F_out > 64) panel_times_wt_split<2>(tile, nrows, a.F_out, static_cast<const uint4 *>(a.epi.wsplit), prow, a.Y, tid, bsp, a.epi.relu, stp);
+      else panel_times_wt_split<1>(tile, nrows, a.F_out, static_cast<const uint4 *>(a.epi.wsplit), prow, a.Y, tid, bsp, a.epi.relu, stp);
+      HG_STAMP_FLUSH();
+      return;
     }
     if (sp.active && !(DBG && (a.debug & 512))) load_bfrag_pre<TW / 4>(a.Wlin, sp.nt_first, tid & 63, bv);
     HG_STAMP(5);
@@ -1920,7 +2118,13 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
         // K = 128, staged: the LDS tile already holds occupancy to five workgroups per CU, so the registers for twelve row
         // gathers in flight per lane cost nothing there (a panel's hop 1 is then two dependent batches instead of three)
         constexpr int UL = LPR >= 32 ? HG_LIN_U32 : 8;
+        // bf16x6 matrix phase (a.epi.wsplit): K = 128, staged, at most 32 rows, and the three operand planes fit the tile region
+        bool split = false;
+        if constexpr (TW == 128) split = a.epi.wsplit && staged && a.rows_cap <= 32 && 3 * kSplitPlaneBytes <= lin_tile_floats(a.cap, a.rows_cap, TW) * 4;
+        if (!split) ad.epi.wsplit = nullptr;
 #define HG_PKL(M, S)                                                                                                          \
+  if constexpr (TW == 128)                                                                                                    \
+    if (split) return launch_lds<fused_packed_kernel<LPR, VEC, UL, true, M, S, false, true, 256, false, true>>(grid, lds_l, stream, ad); \
   return staged ? launch_lds<fused_packed_kernel<LPR, VEC, UL, true, M, S, false, true, 256, false>>(grid, lds_l, stream, ad) \
                 : launch_lds<fused_packed_kernel<LPR, VEC, 8, true, M, S, false, true, 256, true>>(grid, lds_l, stream, ad)
 #ifdef HG_TUNING
@@ -1985,6 +2189,14 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
     }
   }
   return launch_lds<fused_packed_kernel<LPR, VEC, 8, false, true, true, kDbgFallback>>(grid, lds_p, stream, ad);
+}
+
+hipError_t launch_linear_pack_split(int32_t F_out, int32_t F_in, const float *Wlin, void *wsplit, hipStream_t stream) {
+  if (F_out <= 0 || F_in != 128 || (F_out & 15)) return hipErrorInvalidValue;
+  const int64_t n = (int64_t)(F_out >> 4) * (F_in >> 5) * 64;
+  hipLaunchKernelGGL(linear_pack_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, F_out, F_in, Wlin,
+                     static_cast<uint4 *>(wsplit));
+  return hipGetLastError();
 }
 
 hipError_t launch_linear_pack(int32_t F_out, int32_t F_in, const float *Wlin, float *wfrag, hipStream_t stream) {

@@ -40,6 +40,9 @@ class Options:
     backward:    'reference' (forward(grad_out), hgnnaggr.cc:51-64) | 'adjoint' (the exact transpose).
     fuse_linear: 'auto' folds a layer's projection into the aggregation where that is faster
                  (plan.linear_fusion_pays), 'always' wherever the kernel takes the widths, 'never' not.
+    linear_math: 'f32' = the folded projection on fp32 MFMA; 'bf16x6' = at F_in = 128 each fp32 product as six bf16
+                 products on the bf16 MFMA (HG_LIN_BF16X6, include/hg_aggr.h): the same error bound, 3/8 of the matrix-pipe
+                 cycles.  Forward of the fused layer only; every other width and kernel stays fp32 MFMA.
 
     Every operator resolves its options per call -- an explicit `options=` argument, else the innermost
     `with ops.options(...)` block of the calling thread, else the process defaults -- and an autograd node keeps
@@ -48,9 +51,11 @@ class Options:
     variant: str = "auto"
     backward: str = "reference"
     fuse_linear: str = "auto"
+    linear_math: str = "f32"
 
     _CHOICES = {"variant": ("auto", "pull", "fused", "push_atomic", "push_groups"),
-                "backward": ("reference", "adjoint"), "fuse_linear": ("auto", "always", "never")}
+                "backward": ("reference", "adjoint"), "fuse_linear": ("auto", "always", "never"),
+                "linear_math": ("f32", "bf16x6")}
 
     def __post_init__(self):
         for k, allowed in Options._CHOICES.items():
@@ -63,7 +68,9 @@ class Options:
 
 _DEFAULTS_LOCK = threading.Lock()
 _DEFAULTS = Options(fuse_linear=_os.environ["HG_FUSE_LINEAR"]
-                    if _os.environ.get("HG_FUSE_LINEAR") in ("auto", "always", "never") else "auto")  # A/B runs of the drivers
+                    if _os.environ.get("HG_FUSE_LINEAR") in ("auto", "always", "never") else "auto",  # A/B runs of the drivers
+                    linear_math=_os.environ["HG_LINEAR_MATH"]
+                    if _os.environ.get("HG_LINEAR_MATH") in ("f32", "bf16x6") else "f32")
 _TLS = threading.local()
 
 
@@ -271,7 +278,7 @@ class _SumAggrLinear(torch.autograd.Function):
                (mode == "auto" and linear_fusion_pays(F_in, F_out))
         if fuse and variant in ("auto", "pull", "fused"):
             out = plan.aggregate_linear(csrptr_t, indices_t, node_feat, weight.detach().contiguous(),
-                                        degE, degV, W, variant=variant)
+                                        degE, degV, W, variant=variant, math=opt.linear_math)
         else:  # project, then aggregate at F_out (own MFMA rows kernel where it takes the widths)
             wd = weight.detach().contiguous()
             Z = linear_rows(node_feat, wd) if linear_supported(F_in, F_out) and mode != "never" \
@@ -337,7 +344,7 @@ class _AggrResLinear(torch.autograd.Function):
             plan = cached_plan(N, csrptr_t, indices_t)
             T = torch.empty_like(node_feat) if need_t else None
             out = plan.aggregate_linear(csrptr_t, indices_t, node_feat.detach(), Md, degE, degV, W, variant=variant,
-                                        residual=Rd, ca=ca, cb=cbf, relu=relu, t_out=T)
+                                        residual=Rd, ca=ca, cb=cbf, relu=relu, t_out=T, math=opt.linear_math)
         else:
             T = _SumAggrLinear._aggr(csrptr_t, indices_t, node_feat.detach(), degE, degV, W, opt) * ca
             if Rd is not None:

@@ -226,13 +226,15 @@ class Plan:
 
     def aggregate_linear(self, csrptr_t, colind_t, X, weight, degE=None, degV=None, W=None,
                          variant="auto", out=None, workspace=None, packed=None, residual=None, ca=1.0,
-                         cb=0.0, relu=False, t_out=None, bind_scales=True):
+                         cb=0.0, relu=False, t_out=None, bind_scales=True, math="f32"):
         """Y[N, F_out] = Aggr(X) . weight^T in one pass (hg_aggr_linear_f32); weight = nn.Linear.weight,
         [F_out, F_in]; packed = pack_linear(weight) if the caller keeps it across calls.
         With residual / ca / cb / relu / t_out: Y = act((ca * Aggr(X) + cb * residual) . weight^T) and
         t_out receives the bracket (hg_aggr_linear_res_f32: one UniGCNII / UniGIN layer per pass).  cb may be a
         one-element float32 device tensor (a learned scalar such as UniGIN's 1 + eps): the kernel then reads it from
         device memory (hg_aggr_linear_res_dev_f32) -- no read-back to the host, and a captured hipGraph sees its updates.
+        math = 'bf16x6': at F_in = 128 the fused panels' matrix phase computes each fp32 product as six bf16 products
+        (HG_LIN_BF16X6, include/hg_aggr.h: fp32-equivalent error, 3/8 of the matrix-pipe cycles); 'f32': fp32 MFMA.
         Raises HgError(unsupported) for widths the MFMA epilogue does not take."""
         _check_feat(X, "node_feat")
         _check_feat(weight, "weight", device=X.device)
@@ -244,8 +246,13 @@ class Plan:
         F_out = weight.shape[0]
         if packed is None:
             packed = packed_linear_cached(weight)
-        elif packed.numel() != weight.numel():
+        elif packed.numel() not in (weight.numel(), _lib.lib().hg_linear_pack_floats(F_out, F_in, LIN_BF16X6)):
             raise ValueError("packed does not belong to this weight")
+        if math not in ("f32", "bf16x6"):
+            raise ValueError("math must be 'f32' or 'bf16x6', got %r" % (math,))
+        flags = (LIN_RELU if relu else 0)
+        if math == "bf16x6" and F_in == 128 and packed.numel() == _lib.lib().hg_linear_pack_floats(F_out, F_in, LIN_BF16X6):
+            flags |= LIN_BF16X6
         weight = packed
         for name, t, n in (("degE", degE, self.M), ("degV", degV, self.N), ("W", W, self.M)):
             if t is not None:
@@ -276,7 +283,7 @@ class Plan:
             else:
                 fn, cb_arg = _lib.lib().hg_aggr_linear_res_f32, float(cb)
             head = (self._h, F_in, F_out, _ptr(csrptr_t), _ptr(colind_t), _ptr(X), _ptr(degE), _ptr(degV),
-                    _ptr(W), _ptr(weight), _ptr(residual), float(ca), cb_arg, 1 if relu else 0, _ptr(t_out), _ptr(Y))
+                    _ptr(W), _ptr(weight), _ptr(residual), float(ca), cb_arg, flags, _ptr(t_out), _ptr(Y))
             stream = _stream_handle(X.device)
             st = fn(*head, _ptr(workspace), nbytes, _lib.VARIANTS[variant], stream)
             if st == _lib.HG_ERR_WORKSPACE and own_ws:  # stale cached size: see aggregate()
@@ -393,15 +400,22 @@ def linear_fusion_pays(F_in, F_out):
     return linear_supported(F_in, F_out) and (F_in <= 64 or F_out >= F_in)
 
 
+LIN_RELU, LIN_BF16X6 = 1, 2  # include/hg_aggr.h: flags of the linear epilogue
+
+
 def pack_linear(weight):
     """nn.Linear.weight [F_out, F_in] -> the MFMA fragment order hg_aggr_linear_f32 reads
-    (hg_linear_pack_f32; one tiny kernel).  Re-pack after every weight update."""
+    (hg_linear_pack_ex_f32; one or two tiny kernels).  Re-pack after every weight update.
+    At F_in = 128 the buffer also carries the weight's three bf16 planes (HG_LIN_BF16X6), so one packing serves
+    both forms of the matrix phase (aggregate_linear(..., math=))."""
     _check_feat(weight, "weight")
     F_out, F_in = weight.shape
-    wfrag = torch.empty(F_out * F_in, dtype=torch.float32, device=weight.device)
+    L = _lib.lib()
+    wfrag = torch.empty(max(L.hg_linear_pack_floats(F_out, F_in, LIN_BF16X6), F_out * F_in), dtype=torch.float32,
+                        device=weight.device)
     with torch.cuda.device(weight.device):
-        _lib.check(_lib.lib().hg_linear_pack_f32(F_out, F_in, _ptr(weight), _ptr(wfrag),
-                                                 _stream_handle(weight.device)))
+        _lib.check(L.hg_linear_pack_ex_f32(F_out, F_in, _ptr(weight), _ptr(wfrag), LIN_BF16X6,
+                                           _stream_handle(weight.device)))
     return wfrag
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define HG_AGGR_VERSION 400 /* round 4: + hg_aggr_linear_res_dev_f32 */
+#define HG_AGGR_VERSION 410 /* round 4: + hg_aggr_linear_res_dev_f32, HG_LIN_BF16X6 + hg_linear_pack_ex_f32 */
 
 #if defined(__GNUC__)
 #define HG_API __attribute__((visibility("default")))
@@ -282,11 +282,25 @@ HG_API int hg_aggr_fused_f32(const hg_plan *plan, int32_t F,
  * workspace is therefore hg_aggr_linear_workspace_bytes, not hg_plan_workspace_bytes. */
 HG_API int hg_linear_pack_f32(int32_t F_out, int32_t F_in, const float *Wlin, float *wfrag,
                               hg_stream_t stream);
+/* Flags of the `relu` argument of hg_aggr_linear_res(_dev)_f32 (bit 0 is the activation, as before).
+ * HG_LIN_BF16X6: the fused panels' matrix phase at F_in = 128 may compute every fp32 product as six bf16
+ * products (x = h + m + l in bf16 up to 2^-24 |x|, bf16 x bf16 is exact in fp32, the pipe accumulates in fp32;
+ * the three smallest cross terms, < 2^-23 |a b|, are dropped -- below one rounding of the fp32 product) on
+ * v_mfma_f32_16x16x32_bf16: 3/8 of the matrix-pipe cycles of the fp32 form, the same error bound
+ * (tests: both forms within 1e-5 x row mass of the float64 answer; measured maxima side by side in DESIGN.md).
+ * The caller then passes a wfrag of hg_linear_pack_floats(F_out, F_in, HG_LIN_BF16X6) floats filled by
+ * hg_linear_pack_ex_f32 with the same flag: the fp32 fragments (hub vertices, the other variants and every
+ * other width still use them) followed by Wlin's three bf16 planes.  Without the flag nothing changes. */
+#define HG_LIN_RELU 1
+#define HG_LIN_BF16X6 2
+HG_API size_t hg_linear_pack_floats(int32_t F_out, int32_t F_in, int32_t flags);
+HG_API int hg_linear_pack_ex_f32(int32_t F_out, int32_t F_in, const float *Wlin, float *wfrag, int32_t flags,
+                                 hg_stream_t stream);
 HG_API size_t hg_aggr_linear_workspace_bytes(const hg_plan *plan, int32_t F_in);
 /* The same pass with a whole UniGNN layer folded in.  For every vertex v
  *     t     = ca * Aggr(X)[v] + cb * R[v]          (R NULL: t = ca * Aggr(X)[v])
  *     T_out[v] = t                                  (if T_out != NULL; the backward pass needs it)
- *     Y[v]  = act(t * Wlin^T),  act = relu if relu != 0 else identity
+ *     Y[v]  = act(t * Wlin^T),  act = relu if (relu & HG_LIN_RELU) else identity; relu & HG_LIN_BF16X6: see above
  * R and T_out are [N, F_in] row-major, 16-byte aligned.  This is one HyperGsysUniGCNII layer
  * (model/ugsys/unigcnii.py:19-21 with the relu of model/gnn.py:199): Xi = (1-alpha) Xv + alpha X0,
  * out = (1-beta) Xi + beta W(Xi) = Xi * ((1-beta) I + beta W)^T -- pack that matrix as wfrag --

@@ -1180,6 +1180,108 @@ def test_linear_epilogue_own_schedule_on_a_batch(hg, oracle):
     assert list(o64) == list(d64)
 
 
+def _float64_layer(inc, X, Wl, degE=None, degV=None, W=None):
+    """float64 answer of (Aggr(X)) . Wl^T and, per element, the mass of the terms that were added to form it
+    (|A| |X| |Wl^T|): the scale an fp32 evaluation's error is measured against."""
+    import scipy.sparse as sp
+    H = sp.csr_matrix((np.ones(inc.nnz), inc.colind, inc.csrptr), shape=(inc.M, inc.N))
+    se = np.ones(inc.M) if degE is None else degE.astype(np.float64).ravel() * W.astype(np.float64).ravel()
+    sv = np.ones(inc.N) if degV is None else degV.astype(np.float64).ravel()
+    A = sp.diags(sv) @ (H.T @ sp.diags(se) @ H)
+    ref = (A @ X.astype(np.float64)) @ Wl.T.astype(np.float64)
+    mass = (abs(A) @ np.abs(X).astype(np.float64)) @ np.abs(Wl.T).astype(np.float64)
+    return ref, mass
+
+
+@pytest.mark.parametrize("F_out", [128, 64, 112, 48, 16])
+def test_linear_epilogue_bf16x6_is_fp32_equivalent(hg, oracle, F_out):
+    """HG_LIN_BF16X6 (Options.linear_math = 'bf16x6'): at F_in = 128, on the epilogue's own schedule, each fp32 product of
+    the matrix phase is six bf16 products (v_mfma_f32_16x16x32_bf16, fp32 accumulate).  Signed normal features and
+    weights (cancellation).  Both forms: against linear-then-aggregate through the oracle at the tolerance every linear
+    test uses, and against float64 within 1e-6 x the mass of the terms of each element (eight ulps of it; measured
+    2.4e-7 for both forms) -- a tenth of north_star's 1e-5.  The new form must not be less accurate than the fp32 form
+    by more than a rounding, is deterministic, writes the same T_out bits (the bracket is computed before the matrix
+    phase), and really ran (some output bits differ from the fp32 form's)."""
+    from hypergef_amd.plan import Plan
+    inc = synth.replicate_block_diagonal(synth.pubmed_shape(), 8)
+    F = 128
+    X, degE, degV, W, H_ptr, H_ind = _inputs(inc, F, oracle, seed=51, normal=True)
+    rng = np.random.default_rng(52 + F_out)
+    Wl = (rng.standard_normal((F_out, F)) / np.sqrt(F)).astype(np.float32)
+    ptr, ind = _dev(inc.csrptr), _dev(inc.colind)
+    plan = Plan.from_tensors(inc.N, ptr, ind)
+    x, wl = _dev(X), _dev(Wl)
+    sc = (_dev(degE.ravel()), _dev(degV.ravel()), _dev(W))
+    for weighted in (False, True):
+        args = sc if weighted else (None, None, None)
+        ref = _linear_ref(oracle, inc, X, Wl, *((degE, degV, W) if weighted else (None, None, None)), H_ptr, H_ind)
+        f64, mass = _float64_layer(inc, X, Wl, *((degE, degV, W) if weighted else ()))
+        tol = 1e-6 * np.maximum(1.0, mass)
+        errs = {}
+        for math in ("f32", "bf16x6"):
+            Y = plan.aggregate_linear(ptr, ind, x, wl, *args, variant="fused", math=math)
+            _assert_close_linear(Y, ref)
+            e = np.abs(Y.cpu().numpy().astype(np.float64) - f64)
+            assert (e <= tol).all(), "%s: %d elements beyond 1e-6 x mass, worst %g x" % (math, (e > tol).sum(), (e / tol).max())
+            errs[math] = (e / np.maximum(1.0, mass)).max()
+            assert torch.equal(Y, plan.aggregate_linear(ptr, ind, x, wl, *args, variant="fused", math=math))
+            errs[math + "_Y"] = Y
+        assert errs["bf16x6"] <= 1.5 * errs["f32"] + 6e-8, errs
+        assert not torch.equal(errs["f32_Y"], errs["bf16x6_Y"])  # the six-product form ran
+    # one whole layer: residual, relu, T_out
+    R = rng.standard_normal((inc.N, F)).astype(np.float32)
+    out = {}
+    for math in ("f32", "bf16x6"):
+        T = torch.full((inc.N, F), float("nan"), device=DEV)
+        Y = plan.aggregate_linear(ptr, ind, x, wl, sc[0], sc[1], None, variant="fused", residual=_dev(R), ca=0.9, cb=0.1,
+                                  relu=True, t_out=T, math=math)
+        out[math] = (Y, T)
+    assert torch.equal(out["f32"][1], out["bf16x6"][1])
+    agg = oracle.hgnn_check(inc.N, inc.M, F, H_ptr, H_ind, inc.csrptr, inc.colind, X, degE, degV, None)
+    T_ref = (agg * np.float32(0.9) + R * np.float32(0.1)).astype(np.float32)
+    _assert_close(out["bf16x6"][1], T_ref)
+    Y_ref = np.maximum((T_ref.astype(np.float64) @ Wl.T.astype(np.float64)).astype(np.float32), 0)
+    _assert_close_linear(out["bf16x6"][0], Y_ref)
+    assert (out["bf16x6"][0] >= 0).all()
+
+
+def test_linear_bf16x6_falls_back_where_it_does_not_apply(hg, oracle):
+    """The flag is a permission: other widths, a launch-bound hypergraph (default 32-slot tile: the three operand planes
+    do not fit it), the pull variant and hub rows run the fp32 MFMA kernels -- the bits of math = 'f32'.  A packing
+    without the bf16 planes (hg_linear_pack_f32) cannot be used with the flag by mistake."""
+    from hypergef_amd.plan import Plan, _ptr, _stream_handle
+    from hypergef_amd import _lib
+    rng = np.random.default_rng(61)
+    for shape, F, F_out in (("cora", 128, 128), ("cora", 64, 64), ("powerlaw", 128, 64)):
+        inc = _make(shape)
+        X = rng.standard_normal((inc.N, F)).astype(np.float32)
+        Wl = (rng.standard_normal((F_out, F)) / np.sqrt(F)).astype(np.float32)
+        ptr, ind = _dev(inc.csrptr), _dev(inc.colind)
+        plan = Plan.from_tensors(inc.N, ptr, ind)
+        for variant in ("auto", "pull", "fused"):
+            a = plan.aggregate_linear(ptr, ind, _dev(X), _dev(Wl), variant=variant, math="f32")
+            b = plan.aggregate_linear(ptr, ind, _dev(X), _dev(Wl), variant=variant, math="bf16x6")
+            assert torch.equal(a, b), (shape, F, variant)
+    L = _lib.lib()
+    assert L.hg_linear_pack_floats(128, 128, 0) == 128 * 128 and L.hg_linear_pack_floats(128, 128, 2) == 128 * 128 * 5 // 2
+    assert L.hg_linear_pack_floats(64, 64, 2) == 64 * 64  # other widths carry no planes
+    inc = synth.replicate_block_diagonal(synth.pubmed_shape(), 8)
+    ptr, ind = _dev(inc.csrptr), _dev(inc.colind)
+    plan = Plan.from_tensors(inc.N, ptr, ind)
+    X = _dev(rng.standard_normal((inc.N, 128)).astype(np.float32))
+    wl = _dev((rng.standard_normal((128, 128)) / np.sqrt(128)).astype(np.float32))
+    small = torch.empty(128 * 128, device=DEV)
+    _lib.check(L.hg_linear_pack_f32(128, 128, _ptr(wl), _ptr(small), _stream_handle(X.device)))
+    a = plan.aggregate_linear(ptr, ind, X, wl, variant="fused", math="f32")
+    b = plan.aggregate_linear(ptr, ind, X, wl, variant="fused", math="bf16x6", packed=small)  # planes absent: fp32 form
+    assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        plan.aggregate_linear(ptr, ind, X, wl, math="bf16")
+    from hypergef_amd import ops
+    with pytest.raises(ValueError):
+        ops.Options(linear_math="tf32")
+
+
 def test_layer_scalar_from_device_memory(hg, oracle):
     """hg_aggr_linear_res_dev_f32: cb read from a device scalar gives the bits of hg_aggr_linear_res_f32 with the same
     value on the host, on the fused path and on the pull path (standalone rows kernel); a later write to the scalar is

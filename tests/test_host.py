@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol(hg):
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.hg_version() == 400  # HG_AGGR_VERSION: round 4 added hg_aggr_linear_res_dev_f32
+    assert L.hg_version() == 410  # HG_AGGR_VERSION: round 4 added hg_aggr_linear_res_dev_f32, then HG_LIN_BF16X6 + hg_linear_pack_ex_f32
     assert L.hg_status_string(-4) == b"workspace too small"
 
 
