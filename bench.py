@@ -84,6 +84,8 @@ def parse(argv=None):
     p.add_argument("--weighted", action="store_true", help="hgnnaggr (degE, degV, W) instead of H H^T X")
     p.add_argument("--linear-out", type=int, default=0,
                    help="fold the layer's linear feat -> N into the aggregation (hg_aggr_linear_f32: the MFMA path)")
+    p.add_argument("--linear-math", default="f32", choices=["f32", "bf16x6"],
+                   help="with --linear-out at feat 128: the matrix phase on fp32 MFMA, or six bf16 products per fp32 product")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-parity", action="store_true", help="skip the oracle comparison of the timed output")
     p.add_argument("--no-extras", action="store_true", help="skip device-copy / single-graph / sharded extras")
@@ -299,11 +301,13 @@ def parity_report(Y_dev, ref, nrows, inc):
 
 
 def run_config(shape, replicas, F, weighted, variant, steps, warmup, dev, sync, barrier, rank, opts_kw,
-               want_cpu, want_parity, linear_out=0):
+               want_cpu, want_parity, linear_out=0, linear_math="f32"):
     """Build one workload on `dev`, time `steps` aggregations, check the output.  Returns
     (result dict, cpu baseline dict, state for the extras).  linear_out > 0: the aggregation with the
     layer's bias-free linear F -> linear_out folded in (hg_aggr_linear_f32; reference
-    model/ugsys/hgnn.py:22-23), the one MFMA contraction next to the path."""
+    model/ugsys/hgnn.py:22-23), the one MFMA contraction next to the path.  linear_math: 'f32' = fp32 MFMA; 'bf16x6' =
+    each fp32 product of the matrix phase as six bf16 products (HG_LIN_BF16X6, include/hg_aggr.h) -- same checks, same
+    bounds, and the measured error against float64 is on the line beside the fp32 form's."""
     import numpy as np
     import torch
     import hypergef_amd as hg
@@ -343,7 +347,8 @@ def run_config(shape, replicas, F, weighted, variant, steps, warmup, dev, sync, 
         ws = torch.empty(max(int(_lib.lib().hg_aggr_linear_workspace_bytes(plan._h, F)), 256), dtype=torch.uint8, device=dev)
 
         def step():
-            plan.aggregate_linear(ptr, ind, X, weight, degE, degV, W, variant=variant, out=Y, workspace=ws, packed=packed)
+            plan.aggregate_linear(ptr, ind, X, weight, degE, degV, W, variant=variant, out=Y, workspace=ws, packed=packed,
+                                  math=linear_math)
     else:
         Y = torch.empty((inc.N, F), dtype=torch.float32, device=dev)
         ws = torch.empty(max(plan.workspace_bytes(F), 256), dtype=torch.uint8, device=dev)
@@ -365,14 +370,15 @@ def run_config(shape, replicas, F, weighted, variant, steps, warmup, dev, sync, 
     balg = b_alg(inc.N, inc.M, inc.nnz, F, n_w, degV is not None)
     if linear_out:  # Y is [N, linear_out]; the packed weight is read once
         balg += 4 * (inc.N * (linear_out - F) + linear_out * F)
-        dominant = "fused_packed_kernel<..., LIN = true> (hop 1, hop 2, rows . Wlin^T on v_mfma_f32_16x16x4_f32)"
+        dominant = "fused_packed_kernel<..., LIN = true> (hop 1, hop 2, rows . Wlin^T on %s)" % (
+            "v_mfma_f32_16x16x32_bf16, six bf16 products per fp32 product" if linear_math == "bf16x6" else "v_mfma_f32_16x16x4_f32")
     # the whole step's device time over its algorithmic bytes: helper launches count against the
     # step, so a schedule that needs them is not flattered
     step_s = dev_s / steps
     achieved = balg / step_s / 1e9
     name = workload_name(shape, replicas, F) + (", weighted (degE, degV, W)" if weighted else "")
     if linear_out:
-        name += ", aggregation + linear %d->%d (hg_aggr_linear_f32)" % (F, linear_out)
+        name += ", aggregation + linear %d->%d (hg_aggr_linear_f32%s)" % (F, linear_out, ", bf16x6" if linear_math == "bf16x6" else "")
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
@@ -382,7 +388,7 @@ def run_config(shape, replicas, F, weighted, variant, steps, warmup, dev, sync, 
         except Exception:
             traffic = None
     res = {
-        "workload": name, "short": short_name(shape, replicas, F, weighted, linear_out),
+        "workload": name, "short": short_name(shape, replicas, F, weighted, linear_out, linear_math),
         "op": ("(H*H^T*X) * Wlin^T (HGNNConv layer: aggregation + nn.Linear)" if linear_out else
                                  "hgnnaggr (degE, degV, W)" if weighted else "H*H^T*X (aggr_proto)"),
         "vertices": inc.N, "hyperedges": inc.M, "nnz": inc.nnz, "feat_len": F,
@@ -402,7 +408,10 @@ def run_config(shape, replicas, F, weighted, variant, steps, warmup, dev, sync, 
         flops = 2.0 * inc.N * F * linear_out
         res["roofline_mfma"] = {"bound": "mfma", "achieved": flops / step_s / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS,
                                 "unit": "TFLOP/s", "frac": flops / step_s / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                                "dtype": "f32 (v_mfma_f32_16x16x4_f32: exact fp32 in, fp32 accumulate)",
+                                "dtype": ("f32 as six bf16 products per product (v_mfma_f32_16x16x32_bf16, fp32 accumulate); flops = the "
+                                          "fp32 contraction's 2 N K F_out, peak = the fp32 MFMA peak: an fp32-equivalent rate, "
+                                          "not a bf16 pipe utilisation (that is 6 x flops / 2.5 PFLOP/s)" if linear_math == "bf16x6"
+                                          else "f32 (v_mfma_f32_16x16x4_f32: exact fp32 in, fp32 accumulate)"),
                                 "flops_per_step": flops, "traffic": None,
                                 "time_at_peak_ms": flops / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3,
                                 "time_at_hbm_peak_ms": balg / (HBM_PEAK_GBS * 1e9) * 1e3}
@@ -483,11 +492,11 @@ def single_graph_latency(state, F, dev, sync, shape):
     return single
 
 
-def short_name(shape, replicas, F, weighted=False, linear_out=0):
+def short_name(shape, replicas, F, weighted=False, linear_out=0, linear_math="f32"):
     """The name a configuration carries on the final line (the long one, `workload_name`, keys profiles/traffic.json)."""
     s = "powerlaw 1M/4M F=%d" % F if shape == "powerlaw" else "%s x%d F=%d" % (shape, replicas, F)
     if linear_out:
-        s += " +linear%d (MFMA)" % linear_out
+        s += " +linear%d (MFMA%s)" % (linear_out, " bf16x6" if linear_math == "bf16x6" else "")
     return s + (" weighted" if weighted else "")
 
 
@@ -648,6 +657,8 @@ def _config_record(r):
            "parity_ok": r["parity"]["ok"] if "parity" in r else None}
     if "roofline_mfma" in r:
         rec["mfma_frac"] = _r(r["roofline_mfma"]["frac"])
+        if "parity" in r:  # the two forms of the matrix phase side by side: error against float64, per element's mass
+            rec["err_vs_f64"] = _r(r["parity"].get("max_rel_err_vs_float64"), 3)
     return rec
 
 
@@ -885,7 +896,7 @@ def main(argv=None):
         res, cpu, st = run_config(args.shape, args.replicas, F, args.weighted, args.variant, args.steps, args.warmup,
                                   dev, sync, barrier, rank, opts_kw,
                                   want_cpu=one and not args.no_cpu_baseline, want_parity=not args.no_parity,
-                                  linear_out=args.linear_out)  # N > 1: rank 0 still checks its own shard's timed output
+                                  linear_out=args.linear_out, linear_math=args.linear_math)  # N > 1: rank 0 still checks its own shard's timed output
     wall = st["wall"]
     if world > 1:
         t = torch.tensor([wall], dtype=torch.float64, device=dev)
@@ -941,7 +952,7 @@ def main(argv=None):
 
     # every configuration of the line, the headline's own cell first
     head = dict(res)
-    head.setdefault("short", short_name(args.shape, args.replicas, F, args.weighted, args.linear_out))
+    head.setdefault("short", short_name(args.shape, args.replicas, F, args.weighted, args.linear_out, args.linear_math))
     for k in ("plan", "plan_build_s", "fused_schedule"):
         head.pop(k, None)
     configs = [head]
@@ -951,14 +962,16 @@ def main(argv=None):
         # its MFMA path, config 4, the weighted operator
         todo = [("citeseer", 1024, 32, False, 0), ("pubmed", 256, 32, False, 0), ("cora", 256, 128, False, 0),
                 ("citeseer", 256, 128, False, 0), ("pubmed", 64, 128, False, 0), ("pubmed", 64, 128, False, 128),
+                ("pubmed", 64, 128, False, 128, "bf16x6"),
                 ("powerlaw", 1, 64, False, 0), (args.shape, args.replicas, F, True, 0)]
-        for shape, reps, feat, weighted, lin in todo:
-            if (shape, reps, feat, weighted, lin) == (args.shape, args.replicas, F, args.weighted, args.linear_out):
+        for shape, reps, feat, weighted, lin, *rest in todo:
+            lmath = rest[0] if rest else "f32"
+            if (shape, reps, feat, weighted, lin, lmath) == (args.shape, args.replicas, F, args.weighted, args.linear_out, args.linear_math):
                 continue
             try:
                 r, c, s2 = run_config(shape, reps, feat, weighted, "auto", args.config_steps, 10, dev, sync, barrier,
                                       rank, dict(xcd_remap=True), want_cpu=False, want_parity=not args.no_parity,
-                                      linear_out=lin)
+                                      linear_out=lin, linear_math=lmath)
                 del s2
                 torch.cuda.empty_cache()
                 for k in ("plan", "plan_build_s"):
@@ -968,7 +981,7 @@ def main(argv=None):
                     floor_of(r["roofline"], out["device_copy"]["gbs"])
                 configs.append(r)
             except Exception as exc:  # recorded on the line (parity_ok false) and the run fails
-                configs.append({"workload": workload_name(shape, reps, feat), "short": short_name(shape, reps, feat, weighted, lin),
+                configs.append({"workload": workload_name(shape, reps, feat), "short": short_name(shape, reps, feat, weighted, lin, lmath),
                                 "error": "%s: %s" % (type(exc).__name__, str(exc)[:300])})
                 failed = True
     out["configs_detail"] = configs

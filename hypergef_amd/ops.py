@@ -122,6 +122,11 @@ def set_fuse_linear(mode):
     _set_default(fuse_linear=mode)
 
 
+def set_linear_math(mode):
+    """Process default of Options.linear_math."""
+    _set_default(linear_math=mode)
+
+
 def _flat(t):
     # degE / degV / W are read as flat arrays: [M] and [M,1] both valid (SURVEY 8b)
     return None if t is None else t.reshape(-1)

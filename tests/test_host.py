@@ -377,3 +377,14 @@ def test_options_resolution_needs_no_gpu(hg):
         ops.set_fuse_linear("auto")
     with pytest.raises(TypeError):
         ops._opt("pull")
+    # the linear epilogue's arithmetic: fp32 MFMA unless asked otherwise
+    assert base.linear_math == "f32" and ops.Options(linear_math="bf16x6").linear_math == "bf16x6"
+    with pytest.raises(ValueError):
+        ops.Options(linear_math="bf16")
+    ops.set_linear_math("bf16x6")
+    try:
+        assert ops.current_options().linear_math == "bf16x6"
+        with ops.options(linear_math="f32") as o:
+            assert o.linear_math == "f32"
+    finally:
+        ops.set_linear_math("f32")

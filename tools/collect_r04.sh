@@ -18,6 +18,7 @@ run cora128 --shape cora --replicas 256 --feat 128
 run citeseer128 --shape citeseer --replicas 256 --feat 128
 run pubmed128 --shape pubmed --replicas 64 --feat 128
 run pubmed128lin --shape pubmed --replicas 64 --feat 128 --linear-out 128
+run pubmed128lin6 --shape pubmed --replicas 64 --feat 128 --linear-out 128 --linear-math bf16x6
 run powerlaw64 --shape powerlaw --feat 64
 run weighted --shape cora --replicas 1024 --feat 32 --weighted
 python3 - <<'PY'

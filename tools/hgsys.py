@@ -54,6 +54,8 @@ def parse():
                    help="never capture.  Default: a model over ONE launch-bound hypergraph (at most 2^18 incidences, one "
                         "GPU) runs its training step and its forward as hipGraph replays, both backends alike -- eager, "
                         "such an epoch is ~100 launches of host latency; the eager figures are printed beside the replays")
+    p.add_argument("--linear-math", default="f32", choices=["f32", "bf16x6"],
+                   help="hgsys backend, layers fused at nhid = 128 on batches: fp32 MFMA, or six bf16 products per fp32 product")
     p.add_argument("--output", type=str, default=None)
     return p.parse_args()
 
@@ -62,7 +64,8 @@ def main():
     args = parse()
     import torch.distributed as dist
     import hypergef_amd as hg
-    from hypergef_amd import models, synth
+    from hypergef_amd import models, ops, synth
+    ops.set_linear_math(args.linear_math)  # process default: the models resolve their options at every forward
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
