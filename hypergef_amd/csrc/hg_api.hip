@@ -194,7 +194,7 @@ bool lin_caps(const hg_plan *p, int32_t F, bool vec4, int32_t &cap, int32_t &mem
   const int32_t ng = 256 / (hg::fused_tile_row_floats(F, vec4) / 4);
   rows_cap = std::min(cap, 4 * ng);
 #ifdef HG_TUNING
-  if (const char *e = getenv("HG_LIN_ROWS_CAP")) rows_cap = std::max(16, std::min(rows_cap, atoi(e) / 16 * 16));
+  if (const char *e = getenv("HG_LIN_ROWS_CAP")) rows_cap = std::max(16, std::min(rows_cap, atoi(e) / 8 * 8));
 #endif
   cap = std::max(cap, (rows_cap * pct / 100 + 7) / 8 * 8);
   mem_cap = cap * 4;

@@ -688,7 +688,10 @@ __device__ __forceinline__ void panel_times_wt_staged_chunked(float *t, int nrow
 typedef __bf16 hg_bf8 __attribute__((ext_vector_type(8)));
 typedef __bf16 hg_bf2 __attribute__((ext_vector_type(2)));
 typedef float hg_f2 __attribute__((ext_vector_type(2)));
-constexpr int kSplitPlaneBytes = 32 * 256;
+// bytes of one plane: the panel's rows (rows_cap of the schedule, whole groups of 8) of 256 bytes.  A panel of fewer than 32
+// rows still has its second 16-row tile multiplied whole: those reads run into the next plane (the last plane's into the rest of
+// the tile region, launcher-checked) and the rows they produce are never stored.
+__host__ __device__ inline int split_plane_bytes(int rows_cap) { return (rows_cap + 7) / 8 * 8 * 256; }
 
 __device__ __forceinline__ void split_bf16x3(float x, float y, unsigned &h, unsigned &m, unsigned &l) {
   const hg_f2 v{x, y};
@@ -704,14 +707,14 @@ __device__ __forceinline__ void split_bf16x3(float x, float y, unsigned &h, unsi
 // byte offset inside a plane of the 8 bytes that hold columns k .. k + 3 of row r (k a multiple of 4)
 __device__ __forceinline__ int split_off(int r, int k) { return r * 256 + ((((k >> 3) ^ r) & 15) << 4) + ((k & 4) << 1); }
 
-__device__ __forceinline__ void split_store_row(char *planes, int r, int k, const float4 &v) {
+__device__ __forceinline__ void split_store_row(char *planes, int pstride, int r, int k, const float4 &v) {
   unsigned h0, m0, l0, h1, m1, l1;
   split_bf16x3(v.x, v.y, h0, m0, l0);
   split_bf16x3(v.z, v.w, h1, m1, l1);
   char *p = planes + split_off(r, k);
   *reinterpret_cast<uint2 *>(p) = make_uint2(h0, h1);
-  *reinterpret_cast<uint2 *>(p + kSplitPlaneBytes) = make_uint2(m0, m1);
-  *reinterpret_cast<uint2 *>(p + 2 * kSplitPlaneBytes) = make_uint2(l0, l1);
+  *reinterpret_cast<uint2 *>(p + pstride) = make_uint2(m0, m1);
+  *reinterpret_cast<uint2 *>(p + 2 * pstride) = make_uint2(l0, l1);
 }
 
 // Wlin's three planes in fragment order, behind the fp32 fragments of linear_pack_kernel (hub rows and the other
@@ -743,55 +746,93 @@ __device__ __forceinline__ hg_f4 mfma_bf16(const uint4 &a, const uint4 &b, hg_f4
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(hg_bf8, a), __builtin_bit_cast(hg_bf8, b), c, 0, 0, 0);
 }
 
-// NRT row tiles against the wave's NPW column tiles, K = 128 = four steps of 32, (step, column tile) by (step, column
-// tile): the B fragments of the next one (three dwordx4 from the L2) are in flight during this one's 6 * NRT MFMAs; a row
-// tile's A fragments (three ds_read_b128) are read per column tile -- held across both they would be 24 more registers
-// than the six-wave budget has.  The small products go in first.
-template <int NPW, int NRT>
-__device__ __forceinline__ void mfma_rows_split(const char *planes, const uint4 *wsplit, const LinSplit &sp, int NT, int lane,
-                                                const SplitB &bpre, hg_f4 *acc) {
-  constexpr int RPN = 4 / NPW;
-  int nvalid = 0;  // column tiles this wave really has (wave-uniform)
-#pragma unroll
-  for (int ni = 0; ni < NPW; ni++) nvalid += (sp.nt_first + ni * sp.nt_step < NT) ? 1 : 0;
-  SplitB bcur = bpre, bnxt = bpre;
+// Step t of a wave's matrix phase = (k-step t / npw, the wave's column tile t % npw); a column tile past the last one (F_out not
+// a multiple of 64: the last wave has one tile fewer) is clamped -- its products are computed and never written back.
+#ifndef HG_SPLIT_DEPTH
+#define HG_SPLIT_DEPTH 2  // steps of B fragments in registers (12 VGPRs each)
+#endif
+#ifndef HG_SPLIT_APIPE
+#define HG_SPLIT_APIPE 1  // A fragments read one iteration ahead, order pinned
+#endif
+__device__ __forceinline__ SplitB load_bsplit_step(const uint4 *wsplit, const LinSplit &sp, int NT, int npw, int t, int lane) {
+  const int ni = npw == 2 ? (t & 1) : 0, ks = npw == 2 ? (t >> 1) : t;
+  return load_bsplit(wsplit, min(sp.nt_first + ni * sp.nt_step, NT - 1), ks, lane);
+}
+
+// NRT row tiles against the wave's NPW column tiles, K = 128 = four k-steps of 32: 4 * NPW steps of 6 * NRT MFMAs.  The phase is
+// bound by the B fragments' way from the L2 (three dwordx4 per step, ~900 cycles under load against ~200 cycles of MFMAs per
+// step: with one step in flight the phase took 7.5 k cycles of a wave's life for 1.5 k cycles of matrix pipe, stamps in
+// profiles/r04_experiments.md 6).  D steps of fragments live in registers: the first D are loaded by the caller BEFORE hop 2 (they
+// arrive during it), and the registers of a finished step take the fragments of step t + D.  A row tile's A fragments (three
+// ds_read_b128) are read per step -- held across a k-step's column tiles they would be 12 more registers.  The small products
+// go in first.
+template <int NPW, int NRT, int D>
+__device__ __forceinline__ void mfma_rows_split(const char *planes, int pstride, const uint4 *wsplit, const LinSplit &sp, int NT, int lane,
+                                                SplitB (&bq)[D], hg_f4 *acc) {
+  constexpr int RPN = 4 / NPW, NS = 4 * NPW, NI = NS * NRT;
   const int r = lane & 15, kb = lane >> 4;
   const char *prow = planes + (sp.rt_first * 16 + r) * 256;
   const int rstep = sp.rt_step * 16 * 256;
+  // iteration i = (step t, row tile j): six MFMAs on the A fragments of (k-step, row tile) -- three ds_read_b128, planes h, m, l.
+  // An LDS read under six workgroups' traffic takes longer than the 96 cycles of an iteration's MFMAs, and read where they are
+  // used every iteration paid that wait (16 iterations: most of the phase's 7 k cycles for 1.5 k cycles of matrix pipe).  A
+  // second set of fragment registers does not fit the six-wave budget, so the next iteration's fragments are read IN PLACE: a
+  // plane's registers are free once the last MFMA that reads them has issued -- l after the first, m after the third, h after the
+  // sixth -- and its next read goes out right there, three to five MFMAs ahead of its first use.  The scheduling barriers pin that
+  // order (left alone the compiler gathers the three reads in front of the iteration that uses them).
+  auto a_ptr = [&](int i) { const int t = i / NRT, j = i % NRT; return prow + j * rstep + ((((t / NPW * 4 + kb) ^ r) & 15) << 4); };
+  uint4 ah, am, al;
+  {
+    const char *p = a_ptr(0);
+    ah = *reinterpret_cast<const uint4 *>(p);
+    am = *reinterpret_cast<const uint4 *>(p + pstride);
+    al = *reinterpret_cast<const uint4 *>(p + 2 * pstride);
+  }
 #pragma unroll
-  for (int ks = 0; ks < 4; ks++) {
-    const int coff = (((ks * 4 + kb) ^ r) & 15) << 4;
-#pragma unroll
-    for (int ni = 0; ni < NPW; ni++) {
-      if (ni < nvalid) {
-        const int ni2 = ni + 1 < nvalid ? ni + 1 : 0, ks2 = ni + 1 < nvalid ? ks : ks + 1;  // this wave's next (column tile, step)
-        if (ks2 < 4) bnxt = load_bsplit(wsplit, sp.nt_first + ni2 * sp.nt_step, ks2, lane);
-#pragma unroll
-        for (int j = 0; j < NRT; j++) {
-          const char *p = prow + j * rstep + coff;
-          const uint4 ah = *reinterpret_cast<const uint4 *>(p);
-          const uint4 am = *reinterpret_cast<const uint4 *>(p + kSplitPlaneBytes);
-          const uint4 al = *reinterpret_cast<const uint4 *>(p + 2 * kSplitPlaneBytes);
-          hg_f4 c = acc[ni * RPN + j];
-          c = mfma_bf16(al, bcur.h, c);
-          c = mfma_bf16(ah, bcur.l, c);
-          c = mfma_bf16(am, bcur.m, c);
-          c = mfma_bf16(am, bcur.h, c);
-          c = mfma_bf16(ah, bcur.m, c);
-          c = mfma_bf16(ah, bcur.h, c);
-          acc[ni * RPN + j] = c;
-        }
-        bcur = bnxt;
-      }
+  for (int i = 0; i < NI; i++) {
+    const int t = i / NRT, j = i % NRT, ni = t % NPW;
+    const char *pn = a_ptr(i + 1 < NI ? i + 1 : i);
+    const SplitB &b = bq[t % D];
+    hg_f4 c = acc[ni * RPN + j];
+    c = mfma_bf16(al, b.h, c);
+#if HG_SPLIT_APIPE
+    __builtin_amdgcn_sched_barrier(0);
+    if (i + 1 < NI) al = *reinterpret_cast<const uint4 *>(pn + 2 * pstride);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    c = mfma_bf16(am, b.m, c);
+    c = mfma_bf16(am, b.h, c);
+#if HG_SPLIT_APIPE
+    __builtin_amdgcn_sched_barrier(0);
+    if (i + 1 < NI) am = *reinterpret_cast<const uint4 *>(pn + pstride);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    c = mfma_bf16(ah, b.l, c);
+    c = mfma_bf16(ah, b.m, c);
+    c = mfma_bf16(ah, b.h, c);
+    acc[ni * RPN + j] = c;
+#if HG_SPLIT_APIPE
+    __builtin_amdgcn_sched_barrier(0);
+    if (i + 1 < NI) ah = *reinterpret_cast<const uint4 *>(pn);
+#else
+    if (i + 1 < NI) {
+      ah = *reinterpret_cast<const uint4 *>(pn);
+      am = *reinterpret_cast<const uint4 *>(pn + pstride);
+      al = *reinterpret_cast<const uint4 *>(pn + 2 * pstride);
     }
+#endif
+    if (j == NRT - 1 && t + D < NS) bq[t % D] = load_bsplit_step(wsplit, sp, NT, NPW, t + D, lane);
+#if HG_SPLIT_APIPE
+    __builtin_amdgcn_sched_barrier(0);
+#endif
   }
 }
 
 // panel_times_wt_staged_chunked on the split operands: planes = the tile region (operand rows as three bf16 planes); the
 // fp32 results go back into the same region as [rows][K + 4] floats and leave as whole rows.
 template <int NPW>
-__device__ __forceinline__ void panel_times_wt_split(float *t, int nrows, int F_out, const uint4 *wsplit, const int32_t *rowmap,
-                                                     float *Y, int tid, const SplitB &bpre, int relu, Stamper &stp) {
+__device__ __forceinline__ void panel_times_wt_split(float *t, int pstride, int nrows, int F_out, const uint4 *wsplit, const int32_t *rowmap,
+                                                     float *Y, int tid, SplitB (&bq)[HG_SPLIT_DEPTH], int relu, Stamper &stp) {
   constexpr int K = 128, LD = K + 4, RPN = 4 / NPW;
   const int lane = tid & 63;
   const int NT = F_out >> 4, RT = (nrows + 15) >> 4;
@@ -808,11 +849,11 @@ __device__ __forceinline__ void panel_times_wt_split(float *t, int nrows, int F_
       // fragments (a panel of the epilogue's schedule has 29 of its 32 rows on average; the second tile of a shorter one
       // multiplies whatever the planes hold there, and those rows are never stored)
       nrt = RT;
-      mfma_rows_split<NPW, 2>(planes, wsplit, sp, NT, lane, bpre, acc);
+      mfma_rows_split<NPW, 2, HG_SPLIT_DEPTH>(planes, pstride, wsplit, sp, NT, lane, bq, acc);
     } else if (nrt == 2) {
-      mfma_rows_split<NPW, 2>(planes, wsplit, sp, NT, lane, bpre, acc);
+      mfma_rows_split<NPW, 2, HG_SPLIT_DEPTH>(planes, pstride, wsplit, sp, NT, lane, bq, acc);
     } else if (nrt == 1) {
-      mfma_rows_split<NPW, 1>(planes, wsplit, sp, NT, lane, bpre, acc);
+      mfma_rows_split<NPW, 1, HG_SPLIT_DEPTH>(planes, pstride, wsplit, sp, NT, lane, bq, acc);
     }
   }
   HG_STAMP(8);
@@ -1367,8 +1408,15 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
     // the B fragments of this wave's first column tile are issued after hop 2 and fly across the two barriers that
     // follow (issued before hop 2 they would hold K/4 more registers through it: 78 instead of 64 VGPRs)
     [[maybe_unused]] float bv[BPre<TW / 4>::N];
-    [[maybe_unused]] SplitB bsp;
+    [[maybe_unused]] SplitB bsp[HG_SPLIT_DEPTH];
     const LinSplit sp = lin_split(tid >> 6, a.F_out >> 4);
+    if constexpr (SPLIT) {  // the first steps' B fragments (three bf16 planes each): in flight during hop 2
+      if (sp.active) {
+#pragma unroll
+        for (int t = 0; t < HG_SPLIT_DEPTH; t++)
+          bsp[t] = load_bsplit_step(static_cast<const uint4 *>(a.epi.wsplit), sp, a.F_out >> 4, a.F_out > 64 ? 2 : 1, t, tid & 63);
+      }
+    }
     const int rpg = (nrows + NG - 1) / NG;  // <= 4 (launcher)
     const int r0 = min(g * rpg, nrows), r1 = min(r0 + rpg, nrows);
     V outr[4];
@@ -1396,7 +1444,7 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
         }
     }
     if constexpr (SPLIT) {
-      if (sp.active) bsp = load_bsplit(static_cast<const uint4 *>(a.epi.wsplit), sp.nt_first, 0, tid & 63);
+      const int pstride = split_plane_bytes(a.rows_cap);
       if (a.epi.T_out) {  // the combined rows themselves, for the backward pass: straight from the registers
 #pragma unroll
         for (int i = 0; i < 4; i++)
@@ -1406,12 +1454,12 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
       __syncthreads();  // every slot row has been read: the tile becomes the operand's three bf16 planes
 #pragma unroll
       for (int i = 0; i < 4; i++)
-        if (r0 + i < r1) split_store_row(reinterpret_cast<char *>(tile), r0 + i, lcol, outr[i].v);
+        if (r0 + i < r1) split_store_row(reinterpret_cast<char *>(tile), pstride, r0 + i, lcol, outr[i].v);
       __syncthreads();
       HG_STAMP(6);
       HG_STAMP(7);
-      if (a.F_out > 64) panel_times_wt_split<2>(tile, nrows, a.F_out, static_cast<const uint4 *>(a.epi.wsplit), prow, a.Y, tid, bsp, a.epi.relu, stp);
-      else panel_times_wt_split<1>(tile, nrows, a.F_out, static_cast<const uint4 *>(a.epi.wsplit), prow, a.Y, tid, bsp, a.epi.relu, stp);
+      if (a.F_out > 64) panel_times_wt_split<2>(tile, pstride, nrows, a.F_out, static_cast<const uint4 *>(a.epi.wsplit), prow, a.Y, tid, bsp, a.epi.relu, stp);
+      else panel_times_wt_split<1>(tile, pstride, nrows, a.F_out, static_cast<const uint4 *>(a.epi.wsplit), prow, a.Y, tid, bsp, a.epi.relu, stp);
       HG_STAMP_FLUSH();
       return;
     }
@@ -2120,7 +2168,10 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
         constexpr int UL = LPR >= 32 ? HG_LIN_U32 : 8;
         // bf16x6 matrix phase (a.epi.wsplit): K = 128, staged, at most 32 rows, and the three operand planes fit the tile region
         bool split = false;
-        if constexpr (TW == 128) split = a.epi.wsplit && staged && a.rows_cap <= 32 && 3 * kSplitPlaneBytes <= lin_tile_floats(a.cap, a.rows_cap, TW) * 4;
+        if constexpr (TW == 128) {
+          const int ps = split_plane_bytes(a.rows_cap), tile_b = lin_tile_floats(a.cap, a.rows_cap, TW) * 4;
+          split = a.epi.wsplit && staged && a.rows_cap > 0 && a.rows_cap <= 32 && 3 * ps <= tile_b && 2 * ps + 32 * 256 <= (int)lds_l;
+        }
         if (!split) ad.epi.wsplit = nullptr;
 #define HG_PKL(M, S)                                                                                                          \
   if constexpr (TW == 128)                                                                                                    \
@@ -2128,6 +2179,12 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
   return staged ? launch_lds<fused_packed_kernel<LPR, VEC, UL, true, M, S, false, true, 256, false>>(grid, lds_l, stream, ad) \
                 : launch_lds<fused_packed_kernel<LPR, VEC, 8, true, M, S, false, true, 256, true>>(grid, lds_l, stream, ad)
 #ifdef HG_TUNING
+        if constexpr (TW == 128)
+          if (split && (t.fused_debug & 32))  // phase stamps of the bf16x6 form (tools/lin_stamp_probe.py, STAMP_MATH=bf16x6)
+            return launch_lds<fused_packed_kernel<LPR, VEC, UL, true, true, true, true, true, 256, false, true>>(grid, lds_l, stream, ad);
+        if constexpr (TW == 128)
+          if (staged && t.fused_debug == 32)  // ... and of the fp32 form as shipped (staged only, UL gathers in flight)
+            return launch_lds<fused_packed_kernel<LPR, VEC, UL, true, true, true, true, true, 256, false, false>>(grid, lds_l, stream, ad);
         if (t.fused_debug & (768 | 1 | 32))  // ablations of the matrix phase / the gathers (tools/linear_probe.py): diagnostic build only
           return launch_lds<fused_packed_kernel<LPR, VEC, 8, true, true, true, true, true>>(grid, lds_l, stream, ad);
 #endif

@@ -15,6 +15,8 @@ dev = "cuda:0"
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 CASES = [("pubmed", 64, 128, 128), ("pubmed", 64, 128, 64), ("cora", 256, 128, 128), ("citeseer", 256, 128, 128),
          ("pubmed", 64, 128, 32), ("pubmed", 64, 128, 16)]
+if os.environ.get("PROBE_CASES"):  # e.g. 0,2
+    CASES = [CASES[int(i)] for i in os.environ["PROBE_CASES"].split(",")]
 
 
 def timeit(fn, n=30):

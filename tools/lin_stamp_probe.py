@@ -25,7 +25,7 @@ if plain:
     plan.prepare(F)
     ws = torch.empty(max(plan.workspace_bytes(F), 256), dtype=torch.uint8, device=dev)
 run = (lambda: plan.aggregate(ptr, ind, X, out=Y, workspace=ws, variant="fused")) if plain else \
-      (lambda: plan.aggregate_linear(ptr, ind, X, Wl, out=Y, workspace=ws, packed=wfrag))
+      (lambda: plan.aggregate_linear(ptr, ind, X, Wl, out=Y, workspace=ws, packed=wfrag, math=os.environ.get("STAMP_MATH", "f32")))
 for _ in range(3):
     run()
 torch.cuda.synchronize()
