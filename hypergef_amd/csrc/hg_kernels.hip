@@ -768,7 +768,8 @@ __device__ __forceinline__ SplitB load_bsplit_step(const uint4 *wsplit, const Li
 // go in first.
 template <int NPW, int NRT, int D>
 __device__ __forceinline__ void mfma_rows_split(const char *planes, int pstride, const uint4 *wsplit, const LinSplit &sp, int NT, int lane,
-                                                SplitB (&bq)[D], hg_f4 *acc) {
+                                                SplitB (&bq)[D], hg_f4 *acc, int dbg = 0) {  // dbg (diagnostic instance, timing only): 1024 = no
+                                                                                            // B loads in the loop, 2048 = no A reads, 4096 = no MFMAs
   constexpr int RPN = 4 / NPW, NS = 4 * NPW, NI = NS * NRT;
   const int r = lane & 15, kb = lane >> 4;
   const char *prow = planes + (sp.rt_first * 16 + r) * 256;
@@ -794,26 +795,31 @@ __device__ __forceinline__ void mfma_rows_split(const char *planes, int pstride,
     const char *pn = a_ptr(i + 1 < NI ? i + 1 : i);
     const SplitB &b = bq[t % D];
     hg_f4 c = acc[ni * RPN + j];
-    c = mfma_bf16(al, b.h, c);
+    const bool rd = i + 1 < NI && !(dbg & 2048), mm = !(dbg & 4096);
+    if (mm) c = mfma_bf16(al, b.h, c);
 #if HG_SPLIT_APIPE
     __builtin_amdgcn_sched_barrier(0);
-    if (i + 1 < NI) al = *reinterpret_cast<const uint4 *>(pn + 2 * pstride);
+    if (rd) al = *reinterpret_cast<const uint4 *>(pn + 2 * pstride);
     __builtin_amdgcn_sched_barrier(0);
 #endif
-    c = mfma_bf16(am, b.m, c);
-    c = mfma_bf16(am, b.h, c);
+    if (mm) {
+      c = mfma_bf16(am, b.m, c);
+      c = mfma_bf16(am, b.h, c);
+    }
 #if HG_SPLIT_APIPE
     __builtin_amdgcn_sched_barrier(0);
-    if (i + 1 < NI) am = *reinterpret_cast<const uint4 *>(pn + pstride);
+    if (rd) am = *reinterpret_cast<const uint4 *>(pn + pstride);
     __builtin_amdgcn_sched_barrier(0);
 #endif
-    c = mfma_bf16(ah, b.l, c);
-    c = mfma_bf16(ah, b.m, c);
-    c = mfma_bf16(ah, b.h, c);
+    if (mm) {
+      c = mfma_bf16(ah, b.l, c);
+      c = mfma_bf16(ah, b.m, c);
+      c = mfma_bf16(ah, b.h, c);
+    }
     acc[ni * RPN + j] = c;
 #if HG_SPLIT_APIPE
     __builtin_amdgcn_sched_barrier(0);
-    if (i + 1 < NI) ah = *reinterpret_cast<const uint4 *>(pn);
+    if (rd) ah = *reinterpret_cast<const uint4 *>(pn);
 #else
     if (i + 1 < NI) {
       ah = *reinterpret_cast<const uint4 *>(pn);
@@ -821,7 +827,7 @@ __device__ __forceinline__ void mfma_rows_split(const char *planes, int pstride,
       al = *reinterpret_cast<const uint4 *>(pn + 2 * pstride);
     }
 #endif
-    if (j == NRT - 1 && t + D < NS) bq[t % D] = load_bsplit_step(wsplit, sp, NT, NPW, t + D, lane);
+    if (j == NRT - 1 && t + D < NS && !(dbg & 1024)) bq[t % D] = load_bsplit_step(wsplit, sp, NT, NPW, t + D, lane);
 #if HG_SPLIT_APIPE
     __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -832,7 +838,7 @@ __device__ __forceinline__ void mfma_rows_split(const char *planes, int pstride,
 // fp32 results go back into the same region as [rows][K + 4] floats and leave as whole rows.
 template <int NPW>
 __device__ __forceinline__ void panel_times_wt_split(float *t, int pstride, int nrows, int F_out, const uint4 *wsplit, const int32_t *rowmap,
-                                                     float *Y, int tid, SplitB (&bq)[HG_SPLIT_DEPTH], int relu, Stamper &stp) {
+                                                     float *Y, int tid, SplitB (&bq)[HG_SPLIT_DEPTH], int relu, Stamper &stp, int dbg = 0) {
   constexpr int K = 128, LD = K + 4, RPN = 4 / NPW;
   const int lane = tid & 63;
   const int NT = F_out >> 4, RT = (nrows + 15) >> 4;
@@ -849,11 +855,11 @@ __device__ __forceinline__ void panel_times_wt_split(float *t, int pstride, int 
       // fragments (a panel of the epilogue's schedule has 29 of its 32 rows on average; the second tile of a shorter one
       // multiplies whatever the planes hold there, and those rows are never stored)
       nrt = RT;
-      mfma_rows_split<NPW, 2, HG_SPLIT_DEPTH>(planes, pstride, wsplit, sp, NT, lane, bq, acc);
+      mfma_rows_split<NPW, 2, HG_SPLIT_DEPTH>(planes, pstride, wsplit, sp, NT, lane, bq, acc, dbg);
     } else if (nrt == 2) {
-      mfma_rows_split<NPW, 2, HG_SPLIT_DEPTH>(planes, pstride, wsplit, sp, NT, lane, bq, acc);
+      mfma_rows_split<NPW, 2, HG_SPLIT_DEPTH>(planes, pstride, wsplit, sp, NT, lane, bq, acc, dbg);
     } else if (nrt == 1) {
-      mfma_rows_split<NPW, 1, HG_SPLIT_DEPTH>(planes, pstride, wsplit, sp, NT, lane, bq, acc);
+      mfma_rows_split<NPW, 1, HG_SPLIT_DEPTH>(planes, pstride, wsplit, sp, NT, lane, bq, acc, dbg);
     }
   }
   HG_STAMP(8);
@@ -1458,8 +1464,8 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
       __syncthreads();
       HG_STAMP(6);
       HG_STAMP(7);
-      if (a.F_out > 64) panel_times_wt_split<2>(tile, pstride, nrows, a.F_out, static_cast<const uint4 *>(a.epi.wsplit), prow, a.Y, tid, bsp, a.epi.relu, stp);
-      else panel_times_wt_split<1>(tile, pstride, nrows, a.F_out, static_cast<const uint4 *>(a.epi.wsplit), prow, a.Y, tid, bsp, a.epi.relu, stp);
+      if (a.F_out > 64) panel_times_wt_split<2>(tile, pstride, nrows, a.F_out, static_cast<const uint4 *>(a.epi.wsplit), prow, a.Y, tid, bsp, a.epi.relu, stp, DBG ? a.debug : 0);
+      else panel_times_wt_split<1>(tile, pstride, nrows, a.F_out, static_cast<const uint4 *>(a.epi.wsplit), prow, a.Y, tid, bsp, a.epi.relu, stp, DBG ? a.debug : 0);
       HG_STAMP_FLUSH();
       return;
     }
