@@ -1363,8 +1363,7 @@ int hg_linear_rows_f32(int64_t nrows, int32_t F_in, int32_t F_out, const float *
 }
 
 size_t hg_linear_wgrad_workspace_bytes(int64_t nrows, int32_t F_a, int32_t F_b) {
-  if (nrows < 0 || F_a <= 0 || F_b <= 0) return 0;
-  if ((F_a % 16) || (F_b % 16)) return 0;
+  if (nrows < 0 || !hg::wgrad_shape_ok(F_a, F_b)) return 0;
   return (size_t)(hg::wgrad_parts(nrows, F_a, F_b) + 32) * F_a * F_b * sizeof(float);  // + second-level partials
 }
 
@@ -1374,8 +1373,8 @@ int hg_linear_wgrad_f32(int64_t nrows, int32_t F_a, int32_t F_b, const float *A,
     hg::set_error("hg_linear_wgrad_f32: bad argument");
     return HG_ERR_INVALID;
   }
-  if (F_a <= 0 || F_b <= 0 || (F_a % 16) || (F_b % 16) || (F_a / 16) * (F_b / 16) > 16) {
-    hg::set_error("hg_linear_wgrad_f32: need F_a, F_b multiples of 16 with F_a * F_b <= 4096");
+  if (!hg::wgrad_shape_ok(F_a, F_b)) {
+    hg::set_error("hg_linear_wgrad_f32: need F_a, F_b multiples of 16 with F_a * F_b <= 4096, or multiples of 64 up to 512");
     return HG_ERR_UNSUPPORTED;
   }
   if (!workspace || workspace_bytes < hg_linear_wgrad_workspace_bytes(nrows, F_a, F_b)) {

@@ -133,6 +133,7 @@ hipError_t launch_stream_rows(const StreamArgs &a, hipStream_t stream);
 bool fused_linear_ok(const FusedArgs &a);  // can launch_fused run this call's linear epilogue?
 hipError_t launch_linear(const LinearArgs &a, hipStream_t stream);
 int wgrad_parts(int64_t nrows, int32_t Fa, int32_t Fb);
+bool wgrad_shape_ok(int32_t Fa, int32_t Fb);  // <= 16 tiles of 16 x 16, or both widths multiples of 64 up to 512 (64 x 64 blocks)
 hipError_t launch_wgrad(int64_t nrows, int32_t Fa, int32_t Fb, const float *A, const float *B, float *C,
                         float *partial, hipStream_t stream);
 hipError_t launch_linear_pack(int32_t F_out, int32_t F_in, const float *Wlin, float *wfrag, hipStream_t stream);

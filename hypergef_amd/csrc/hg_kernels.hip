@@ -1033,8 +1033,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KSTEPS >= 3
 // workgroups through one partial matrix each and a second kernel (fixed order: deterministic).
 template <int TA, int TB>
 __global__ __launch_bounds__(256) void wgrad_kernel(const float *A, const float *B, float *partial, int64_t N,
-                                                    int64_t rows_per_wg) {
+                                                    int64_t rows_per_wg, int lda, int ldb, int nbb) {
   constexpr int FA = TA * 16, FB = TB * 16;
+  // blockIdx.y = (block of FA columns of A, block of FB columns of B) of a wider product (lda, ldb = the operands' row
+  // strides): C's FA x FB blocks are independent contractions over the same rows
+  A += (blockIdx.y / nbb) * FA;
+  B += (blockIdx.y % nbb) * FB;
   __shared__ float red[FA * FB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int kk = lane >> 4, c = lane & 15;
@@ -1073,8 +1077,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *A, const float 
         for (int q = 0; q < T; q++) dst[q] = ok ? p[q] : 0.f;
       }
     };
-    fetch(A + row * FA + c * TA, a, std::integral_constant<int, TA>{});
-    fetch(B + row * FB + c * TB, b, std::integral_constant<int, TB>{});
+    fetch(A + row * lda + c * TA, a, std::integral_constant<int, TA>{});
+    fetch(B + row * ldb + c * TB, b, std::integral_constant<int, TB>{});
   };
   float a2[TA], b2[TB];
   if (r0 < r1) load(r0, a0, b0);
@@ -1113,20 +1117,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *A, const float 
     }
     __syncthreads();
   }
-  float *out = partial + (int64_t)blockIdx.x * FA * FB;
+  float *out = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * FA * FB;
   for (int i = threadIdx.x; i < FA * FB; i += 256) out[i] = red[i];
 }
 
 // out[c * n + i] = sum over parts p = c, c + nchunks, c + 2 nchunks, ... of partial[p * n + i]
 // (blockIdx.y = c).  Run twice -- nparts -> 32 chunks -> 1 -- so that the sum over a thousand
 // partial matrices is spread over 512 workgroups instead of sixteen.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *partial, int nparts, int n, float *out) {
+// fb > 0 (last level of a blocked product): element i of the fb-column block goes to out[(i / fb) * ldc + i % fb].
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *partial, int nparts, int n, float *out, int fb, int ldc) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int c = blockIdx.y, nchunks = gridDim.y;
   float s = 0.f;
   for (int p = c; p < nparts; p += nchunks) s += partial[(int64_t)p * n + i];
-  out[(int64_t)c * n + i] = s;
+  if (fb > 0) out[(int64_t)(i / fb) * ldc + (i % fb)] = s;
+  else out[(int64_t)c * n + i] = s;
 }
 
 // Packed form of the fused panel kernel.  The plan hands every panel over as ONE
@@ -2272,7 +2278,17 @@ hipError_t launch_linear_pack(int32_t F_out, int32_t F_in, const float *Wlin, fl
 
 // One resident round of workgroups: the accumulators (4 registers per output tile) decide how
 // many fit a CU -- 64 x 64: three, 32 x 32: eight.
+// Products beyond sixteen 16 x 16 tiles (the accumulators of one wave) run as independent 64 x 64 blocks of the output over the
+// same rows (blockIdx.y; both widths multiples of 64): 128 x 128 = four blocks, every operand row read twice.  rocBLAS takes
+// 1.11 ms for [128 x 693 k] . [693 k x 128] (35.8 % of a 4-layer nhid = 128 HGNN epoch under rocprofv3).
+bool wgrad_blocked(int32_t Fa, int32_t Fb) { return (Fa / 16) * (Fb / 16) > 16; }
+bool wgrad_shape_ok(int32_t Fa, int32_t Fb) {
+  if (Fa <= 0 || Fb <= 0 || (Fa & 15) || (Fb & 15)) return false;
+  if (!wgrad_blocked(Fa, Fb)) return true;
+  return (Fa % 64) == 0 && (Fb % 64) == 0 && Fa <= 512 && Fb <= 512;
+}
 int wgrad_parts(int64_t nrows, int32_t Fa, int32_t Fb) {
+  if (wgrad_blocked(Fa, Fb)) Fa = Fb = 64;
   const int tiles = (Fa / 16) * (Fb / 16);
   const int64_t cap = tiles <= 4 ? 2048 : (tiles <= 8 ? 1024 : 768);
   return (int)std::max<int64_t>(1, std::min<int64_t>(cap, (nrows + 63) / 64));
@@ -2280,13 +2296,16 @@ int wgrad_parts(int64_t nrows, int32_t Fa, int32_t Fb) {
 
 hipError_t launch_wgrad(int64_t nrows, int32_t Fa, int32_t Fb, const float *A, const float *B, float *C,
                         float *partial, hipStream_t stream) {
-  if ((Fa & 15) || (Fb & 15) || Fa <= 0 || Fb <= 0 || (Fa / 16) * (Fb / 16) > 16) return hipErrorInvalidValue;
+  if (!wgrad_shape_ok(Fa, Fb)) return hipErrorInvalidValue;
+  const bool blocked = wgrad_blocked(Fa, Fb);
+  const int32_t Ba = blocked ? 64 : Fa, Bb = blocked ? 64 : Fb;  // block of the output one workgroup's accumulators hold
+  const int nba = Fa / Ba, nbb = Fb / Bb, nblocks = nba * nbb;
   const int nparts = wgrad_parts(nrows, Fa, Fb);
   int64_t rows_per_wg = (nrows + nparts - 1) / nparts;
   rows_per_wg = (rows_per_wg + 15) & ~(int64_t)15;
 #define HG_WG(TA_, TB_)                                                                                          \
-  if (Fa == 16 * TA_ && Fb == 16 * TB_) {                                                                        \
-    hipLaunchKernelGGL((wgrad_kernel<TA_, TB_>), dim3(nparts), dim3(256), 0, stream, A, B, partial, nrows, rows_per_wg); \
+  if (Ba == 16 * TA_ && Bb == 16 * TB_) {                                                                        \
+    hipLaunchKernelGGL((wgrad_kernel<TA_, TB_>), dim3(nparts, nblocks), dim3(256), 0, stream, A, B, partial, nrows, rows_per_wg, Fa, Fb, nbb); \
   } else
   HG_WG(1, 1) HG_WG(1, 2) HG_WG(2, 1) HG_WG(2, 2) HG_WG(1, 4) HG_WG(4, 1) HG_WG(2, 4) HG_WG(4, 2) HG_WG(4, 4)
   HG_WG(1, 8) HG_WG(8, 1) HG_WG(2, 8) HG_WG(8, 2) HG_WG(1, 3) HG_WG(3, 1) HG_WG(3, 3) HG_WG(3, 4) HG_WG(4, 3)
@@ -2294,14 +2313,19 @@ hipError_t launch_wgrad(int64_t nrows, int32_t Fa, int32_t Fb, const float *A, c
 #undef HG_WG
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  const int n = Fa * Fb;
+  const int n = Ba * Bb;
   const int mid = nparts > 64 ? 32 : 1;  // second-level partials live behind the first-level ones
-  if (mid > 1) {
-    float *p2 = partial + (int64_t)nparts * n;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 255) / 256, mid), dim3(256), 0, stream, partial, nparts, n, p2);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 255) / 256, 1), dim3(256), 0, stream, p2, mid, n, C);
-  } else {
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 255) / 256, 1), dim3(256), 0, stream, partial, nparts, n, C);
+  float *p2 = partial + (int64_t)nblocks * nparts * n;
+  for (int b = 0; b < nblocks; b++) {  // fixed order of additions per element: deterministic
+    const float *pb = partial + (int64_t)b * nparts * n;
+    float *cb = C + (int64_t)(b / nbb) * Ba * Fb + (b % nbb) * Bb;
+    if (mid > 1) {
+      float *q = p2 + (int64_t)b * mid * n;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 255) / 256, mid), dim3(256), 0, stream, pb, nparts, n, q, 0, 0);
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 255) / 256, 1), dim3(256), 0, stream, q, mid, n, cb, Bb, Fb);
+    } else {
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 255) / 256, 1), dim3(256), 0, stream, pb, nparts, n, cb, Bb, Fb);
+    }
   }
   return hipGetLastError();
 }

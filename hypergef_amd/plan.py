@@ -474,7 +474,13 @@ def linear_rows(X, weight, packed=None, out=None):
 
 
 def wgrad_supported(F_a, F_b):
-    return F_a > 0 and F_b > 0 and F_a % 16 == 0 and F_b % 16 == 0 and (F_a // 16) * (F_b // 16) <= 16
+    """hg_linear_wgrad_f32's shapes: at most sixteen 16 x 16 tiles (one workgroup's accumulators), or both widths
+    multiples of 64 up to 512 (64 x 64 blocks of the output)."""
+    if F_a <= 0 or F_b <= 0 or F_a % 16 or F_b % 16:
+        return False
+    if (F_a // 16) * (F_b // 16) <= 16:
+        return True
+    return F_a % 64 == 0 and F_b % 64 == 0 and F_a <= 512 and F_b <= 512
 
 
 def linear_wgrad(A, B):

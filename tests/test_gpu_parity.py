@@ -784,7 +784,10 @@ def test_linear_wgrad_kernel(hg):
     from hypergef_amd import _lib
     rng = np.random.default_rng(4)
     for N, Fa, Fb in ((1, 16, 16), (63, 64, 64), (4097, 64, 64), (100000, 32, 128), (70001, 128, 32), (5000, 48, 48),
-                      (333, 64, 16)):
+                      (333, 64, 16),
+                      # beyond one workgroup's accumulators: 64 x 64 blocks of the output (blockIdx.y), operands read with
+                      # their own row strides
+                      (50001, 128, 128), (7, 128, 128), (20000, 128, 64), (20000, 64, 192), (3000, 256, 128)):
         assert wgrad_supported(Fa, Fb)
         A = rng.standard_normal((N, Fa)).astype(np.float32)
         B = rng.standard_normal((N, Fb)).astype(np.float32)
@@ -794,9 +797,9 @@ def test_linear_wgrad_kernel(hg):
         assert np.abs(C - ref).max() <= 2e-5 * max(1.0, scale * 4), (N, Fa, Fb, np.abs(C - ref).max())
         C2 = linear_wgrad(_dev(A), _dev(B)).cpu().numpy()
         assert np.array_equal(C, C2)  # fixed reduction order
-    assert not wgrad_supported(128, 128) and not wgrad_supported(20, 16)
+    assert wgrad_supported(128, 128) and not wgrad_supported(20, 16) and not wgrad_supported(128, 48) and not wgrad_supported(1024, 64)
     with pytest.raises(_lib.HgError):
-        linear_wgrad(torch.zeros(10, 128, device=DEV), torch.zeros(10, 128, device=DEV))
+        linear_wgrad(torch.zeros(10, 128, device=DEV), torch.zeros(10, 48, device=DEV))
 
 
 def test_own_linear_module_matches_nn_linear(hg):

@@ -21,7 +21,8 @@ def timed(fn, n=20):
     return s.elapsed_time(e) / n
 
 
-for N, Fa, Fb in ((693248, 64, 64), (2772992, 32, 32), (2772992, 64, 64), (693248, 32, 128), (1261888, 64, 64)):
+for N, Fa, Fb in ((693248, 64, 64), (2772992, 32, 32), (2772992, 64, 64), (693248, 32, 128), (1261888, 64, 64),
+                  (693248, 128, 128), (1261888, 128, 128), (693248, 128, 64), (693248, 256, 128)):
     A = torch.randn(N, Fa, device=dev)
     B = torch.randn(N, Fb, device=dev)
     t_own = timed(lambda: linear_wgrad(A, B))
