@@ -1033,16 +1033,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KSTEPS >= 3
 // workgroups through one partial matrix each and a second kernel (fixed order: deterministic).
 template <int TA, int TB>
 __global__ __launch_bounds__(256) void wgrad_kernel(const float *A, const float *B, float *partial, int64_t N,
-                                                    int64_t rows_per_wg, int lda, int ldb, int nbb) {
+                                                    int64_t rows_per_wg, int lda, int ldb, int nbb, int nblocks, int nparts) {
   constexpr int FA = TA * 16, FB = TB * 16;
-  // blockIdx.y = (block of FA columns of A, block of FB columns of B) of a wider product (lda, ldb = the operands' row
-  // strides): C's FA x FB blocks are independent contractions over the same rows
-  A += (blockIdx.y / nbb) * FA;
-  B += (blockIdx.y % nbb) * FB;
+  // A wider product (lda, ldb = the operands' row strides) runs as nblocks independent FA x FB blocks of C over the same rows.
+  // The blocks of one row range (part) are dealt to the SAME XCD, eight workgroup ids apart -- dispatched together, so the
+  // second read of an operand's half rows is an L2 hit instead of a second trip to HBM: workgroup id = xcd + 8 (nblocks q + b)
+  // for part 8 q + xcd, block b (nparts a multiple of 8 then, launcher).
+  int part = blockIdx.x, blk = 0;
+  if (nblocks > 1) {
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    blk = k % nblocks;
+    part = (k / nblocks) * 8 + xcd;
+  }
+  A += (blk / nbb) * FA;
+  B += (blk % nbb) * FB;
   __shared__ float red[FA * FB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int kk = lane >> 4, c = lane & 15;
-  const int64_t wg0 = (int64_t)blockIdx.x * rows_per_wg;
+  const int64_t wg0 = min(N, (int64_t)part * rows_per_wg);
   const int64_t wg1 = min(N, wg0 + rows_per_wg);
   const int64_t per_wave = (rows_per_wg / 4 + 3) & ~(int64_t)3;  // multiple of 4 rows
   const int64_t r0 = min(wg1, wg0 + wave * per_wave), r1 = min(wg1, r0 + per_wave);
@@ -1117,7 +1125,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *A, const float 
     }
     __syncthreads();
   }
-  float *out = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * FA * FB;
+  float *out = partial + ((int64_t)blk * nparts + part) * FA * FB;
   for (int i = threadIdx.x; i < FA * FB; i += 256) out[i] = red[i];
 }
 
@@ -2288,10 +2296,12 @@ bool wgrad_shape_ok(int32_t Fa, int32_t Fb) {
   return (Fa % 64) == 0 && (Fb % 64) == 0 && Fa <= 512 && Fb <= 512;
 }
 int wgrad_parts(int64_t nrows, int32_t Fa, int32_t Fb) {
-  if (wgrad_blocked(Fa, Fb)) Fa = Fb = 64;
+  const bool blocked = wgrad_blocked(Fa, Fb);
+  if (blocked) Fa = Fb = 64;
   const int tiles = (Fa / 16) * (Fb / 16);
   const int64_t cap = tiles <= 4 ? 2048 : (tiles <= 8 ? 1024 : 768);
-  return (int)std::max<int64_t>(1, std::min<int64_t>(cap, (nrows + 63) / 64));
+  const int n = (int)std::max<int64_t>(1, std::min<int64_t>(cap, (nrows + 63) / 64));
+  return blocked ? (n + 7) / 8 * 8 : n;  // blocked: whole groups of eight parts (one per XCD; a part past the rows adds zeros)
 }
 
 hipError_t launch_wgrad(int64_t nrows, int32_t Fa, int32_t Fb, const float *A, const float *B, float *C,
@@ -2300,12 +2310,12 @@ hipError_t launch_wgrad(int64_t nrows, int32_t Fa, int32_t Fb, const float *A, c
   const bool blocked = wgrad_blocked(Fa, Fb);
   const int32_t Ba = blocked ? 64 : Fa, Bb = blocked ? 64 : Fb;  // block of the output one workgroup's accumulators hold
   const int nba = Fa / Ba, nbb = Fb / Bb, nblocks = nba * nbb;
-  const int nparts = wgrad_parts(nrows, Fa, Fb);
+  const int nparts = wgrad_parts(nrows, Fa, Fb);  // blocked: a multiple of 8
   int64_t rows_per_wg = (nrows + nparts - 1) / nparts;
   rows_per_wg = (rows_per_wg + 15) & ~(int64_t)15;
 #define HG_WG(TA_, TB_)                                                                                          \
   if (Ba == 16 * TA_ && Bb == 16 * TB_) {                                                                        \
-    hipLaunchKernelGGL((wgrad_kernel<TA_, TB_>), dim3(nparts, nblocks), dim3(256), 0, stream, A, B, partial, nrows, rows_per_wg, Fa, Fb, nbb); \
+    hipLaunchKernelGGL((wgrad_kernel<TA_, TB_>), dim3(nparts * nblocks), dim3(256), 0, stream, A, B, partial, nrows, rows_per_wg, Fa, Fb, nbb, nblocks, nparts); \
   } else
   HG_WG(1, 1) HG_WG(1, 2) HG_WG(2, 1) HG_WG(2, 2) HG_WG(1, 4) HG_WG(4, 1) HG_WG(2, 4) HG_WG(4, 2) HG_WG(4, 4)
   HG_WG(1, 8) HG_WG(8, 1) HG_WG(2, 8) HG_WG(8, 2) HG_WG(1, 3) HG_WG(3, 1) HG_WG(3, 3) HG_WG(3, 4) HG_WG(4, 3)

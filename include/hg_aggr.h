@@ -328,7 +328,7 @@ HG_API int hg_aggr_linear_res_dev_f32(const hg_plan *plan, int32_t F_in, int32_t
  * Every element of A and B is read once, straight into fp32 MFMA operands; workgroups are reduced
  * in a fixed order (deterministic).  F_a, F_b multiples of 16 with F_a * F_b <= 4096 -- one workgroup's
  * accumulators hold the whole output -- or both multiples of 64 up to 512: 64 x 64 blocks of the output as
- * independent contractions over the same rows (128 x 128: every operand row read twice; 2.5 x rocBLAS).  Else
+ * independent contractions over the same rows (128 x 128: 3 x rocBLAS).  Else
  * HG_ERR_UNSUPPORTED: use a BLAS.  workspace = hg_linear_wgrad_workspace_bytes (0 = unsupported shape). */
 HG_API size_t hg_linear_wgrad_workspace_bytes(int64_t nrows, int32_t F_a, int32_t F_b);
 HG_API int hg_linear_wgrad_f32(int64_t nrows, int32_t F_a, int32_t F_b, const float *A, const float *B,
