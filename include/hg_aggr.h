@@ -290,7 +290,9 @@ HG_API int hg_linear_pack_f32(int32_t F_out, int32_t F_in, const float *Wlin, fl
  * (tests: both forms within 1e-5 x row mass of the float64 answer; measured maxima side by side in DESIGN.md).
  * The caller then passes a wfrag of hg_linear_pack_floats(F_out, F_in, HG_LIN_BF16X6) floats filled by
  * hg_linear_pack_ex_f32 with the same flag: the fp32 fragments (hub vertices, the other variants and every
- * other width still use them) followed by Wlin's three bf16 planes.  Without the flag nothing changes. */
+ * other width still use them) followed by Wlin's three bf16 planes.  Without the flag nothing changes.
+ * Range: bf16 keeps fp32's exponent, so finite operands below 2^127 in magnitude behave as in the fp32 form;
+ * an infinite operand (or one that rounds to infinity in bf16) yields NaN where the fp32 form yields +-inf. */
 #define HG_LIN_RELU 1
 #define HG_LIN_BF16X6 2
 HG_API size_t hg_linear_pack_floats(int32_t F_out, int32_t F_in, int32_t flags);
