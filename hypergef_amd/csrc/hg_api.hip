@@ -178,9 +178,7 @@ double small_graph_cost(const hg::FusedSched &f) {
 // (F = 128: 32, F = 64: 64 -- whole tiles) and gives the panel half as many slots again, so that the rows run out before
 // the slots do (pubmed-shape, F = 128: 32 slots hold 24 rows on average; 48 hold the 32).  lin_caps() returns false
 // where the default schedule is already that shape (F = 32: 128 rows of 128 slots) or the caller fixed the tile.
-// mode 2 (bf16x6 matrix phase only): panels of 512 threads -- sixteen lane groups, 64 rows, 96 slots: a wave's B fragments serve
-// four row tiles' worth of the chip instead of two (half the Wlin traffic per row), half the panels.
-bool lin_caps(const hg_plan *p, int32_t F, bool vec4, int32_t &cap, int32_t &mem_cap, int32_t &rows_cap, int mode = 1) {
+bool lin_caps(const hg_plan *p, int32_t F, bool vec4, int32_t &cap, int32_t &mem_cap, int32_t &rows_cap) {
   // F = 128 only.  At F = 64 the default panels hold 53 of their 64 rows already, and every larger tile lost there (cora
   // x1024 64 -> 64: 0.463 ms default, 0.469-0.475 with 80 slots, 0.485-0.492 with 96).  At F = 32 a cap of 112 rows (seven
   // tiles) lets the operand rows fit the slot tile's 16 KB -- 19 600 instead of 21 648 bytes of LDS, eight resident
@@ -193,8 +191,7 @@ bool lin_caps(const hg_plan *p, int32_t F, bool vec4, int32_t &cap, int32_t &mem
 #endif
   if (pct <= 0) return false;
   fused_caps(p, F, vec4, cap, mem_cap);
-  const int32_t ng = (mode == 2 ? 512 : 256) / (hg::fused_tile_row_floats(F, vec4) / 4);
-  if (mode == 2) cap *= 2;
+  const int32_t ng = 256 / (hg::fused_tile_row_floats(F, vec4) / 4);
   rows_cap = std::min(cap, 4 * ng);
 #ifdef HG_TUNING
   if (const char *e = getenv("HG_LIN_ROWS_CAP")) rows_cap = std::max(16, std::min(rows_cap, atoi(e) / 8 * 8));
@@ -207,13 +204,13 @@ bool lin_caps(const hg_plan *p, int32_t F, bool vec4, int32_t &cap, int32_t &mem
   return true;
 }
 
-int get_fused(const hg_plan *cp, int32_t F, bool vec4, const hg::FusedSched **out, int lin = 0) {
+int get_fused(const hg_plan *cp, int32_t F, bool vec4, const hg::FusedSched **out, bool lin = false) {
   hg_plan *p = const_cast<hg_plan *>(cp);
   int32_t cap, mem_cap, rows_cap = 0;
-  if (lin && !lin_caps(p, F, vec4, cap, mem_cap, rows_cap, lin)) lin = 0;
+  if (lin && !lin_caps(p, F, vec4, cap, mem_cap, rows_cap)) lin = false;
   if (!lin) fused_caps(p, F, vec4, cap, mem_cap);
   const int32_t row_floats = hg::fused_tile_row_floats(F, vec4);
-  const int32_t ng = (lin == 2 ? 512 : 256) / (row_floats / (vec4 ? 4 : 1));  // lane groups per workgroup
+  const int32_t ng = 256 / (row_floats / (vec4 ? 4 : 1));  // lane groups per workgroup
   // The hub pass reads X and the materialised table through buffer descriptors (row index below 2^24,
   // tables below 2 GiB) and exists for 16-byte lanes of at least 16 floats per row.
   // (rows of the materialised table are masked to 24 bits in the round records too, and n_mat <= M)
@@ -919,7 +916,7 @@ __attribute__((visibility("default"))) int hg_debug_mfma_rate(int32_t blocks, in
 // own one -- out = {panels, rows, rows padded to 16-row tiles, member entries, slots, cap, rows_cap, n_mat, hop-1 steps}.
 __attribute__((visibility("default"))) int hg_debug_fused_shape(const hg_plan *p, int32_t F, int32_t lin, int64_t *out9) {
   const hg::FusedSched *f = nullptr;
-  int rc = get_fused(p, F, plan_vec4(p, F), &f, lin);
+  int rc = get_fused(p, F, plan_vec4(p, F), &f, lin != 0);
   if (rc != HG_OK) return rc;
   int64_t rows = 0, padded = 0, slots = 0;
   for (const auto &pn : f->panels) {
@@ -1073,11 +1070,7 @@ static int aggr_impl(const hg_plan *plan, int32_t F, const int32_t *csrptr_t,
       // schedule's binding -- gathered here on first use, on this call's stream, which every later use is ordered behind
       // or waits for through the caller's binding event (plan.py, _bind_scales)
       const hg::FusedSched *fl = nullptr;
-      int lmode = 1;
-#ifdef HG_TUNING
-      if (lin->epi.wsplit && getenv("HG_LIN_PANEL512")) lmode = 2;  // experiment: 64-row panels on 512 threads (bf16x6 form only)
-#endif
-      if ((rc = get_fused(plan, F, vec4, &fl, lmode)) != HG_OK) return rc;
+      if ((rc = get_fused(plan, F, vec4, &fl, true)) != HG_OK) return rc;
       if (fl != f && fl->fixups.empty()) {
         const bool dflt_bound = (degE || degV || W) && f->bound_degE == degE && f->bound_W == W && f->bound_degV == degV;
         if (dflt_bound && !(fl->bound_degE == degE && fl->bound_W == W && fl->bound_degV == degV)) {
@@ -1399,7 +1392,7 @@ static size_t linear_base_bytes(const hg_plan *plan, int32_t F_in) {
   const hg::FusedSched *f = nullptr;
   const bool vec4 = plan_vec4(plan, F_in);
   if (pick_variant(plan, F_in, vec4, &variant, &f) == HG_OK && variant == HG_VARIANT_FUSED && f && f->fixups.empty())
-    (void)get_fused(plan, F_in, vec4, &f, 1);
+    (void)get_fused(plan, F_in, vec4, &f, true);
   return workspace_need(plan, F_in);
 }
 

@@ -395,9 +395,9 @@ struct LinSplit {  // how the four waves share (column tile, row tile) space
   int nt_first, nt_step, rt_first, rt_step;
   bool active;
 };
-__device__ __forceinline__ LinSplit lin_split(int wid, int NT, int nwaves = 4) {
+__device__ __forceinline__ LinSplit lin_split(int wid, int NT) {
   const int nwn = NT >= 4 ? 4 : (NT == 3 ? 3 : NT);  // waves across column tiles
-  const int nwr = nwaves / nwn;                      // waves across row tiles (four waves, three column tiles: the fourth idles)
+  const int nwr = NT >= 3 ? 1 : 4 / nwn;             // waves across row tiles
   LinSplit s;
   s.nt_first = wid % nwn;
   s.nt_step = nwn;
@@ -836,24 +836,25 @@ __device__ __forceinline__ void mfma_rows_split(const char *planes, int pstride,
 
 // panel_times_wt_staged_chunked on the split operands: planes = the tile region (operand rows as three bf16 planes); the
 // fp32 results go back into the same region as [rows][K + 4] floats and leave as whole rows.
-template <int NPW, int BS = 256>
+template <int NPW>
 __device__ __forceinline__ void panel_times_wt_split(float *t, int pstride, int nrows, int F_out, const uint4 *wsplit, const int32_t *rowmap,
                                                      float *Y, int tid, SplitB (&bq)[HG_SPLIT_DEPTH], int relu, Stamper &stp, int dbg = 0) {
   constexpr int K = 128, LD = K + 4, RPN = 4 / NPW;
   const int lane = tid & 63;
   const int NT = F_out >> 4, RT = (nrows + 15) >> 4;
-  const LinSplit sp = lin_split(tid >> 6, NT, BS / 64);
+  const LinSplit sp = lin_split(tid >> 6, NT);
   hg_f4 acc[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) acc[j] = hg_f4{0.f, 0.f, 0.f, 0.f};
-  int nrt = 0;  // row tiles of this wave that exist (the results of the others are not written back)
+  int nrt = 0;
   if (sp.active) {
-    nrt = min(2, max(0, (RT - sp.rt_first + sp.rt_step - 1) / sp.rt_step));  // at most two per wave (launcher)
+    nrt = min(2, max(0, (RT - sp.rt_first + sp.rt_step - 1) / sp.rt_step));  // at most 32 rows (launcher)
     const char *planes = reinterpret_cast<const char *>(t);
     if constexpr (NPW == 2) {
-      // F_out > 64: both row tiles always, no branch around the preloaded fragments (a panel of the epilogue's schedule has 29
-      // of its 32 rows on average; a tile past the rows multiplies whatever the planes hold there -- inside the tile region,
-      // launcher-checked -- and is never stored)
+      // F_out > 64: every wave walks the row tiles from 0 (lin_split) -- both tiles always, no branch around the preloaded
+      // fragments (a panel of the epilogue's schedule has 29 of its 32 rows on average; the second tile of a shorter one
+      // multiplies whatever the planes hold there, and those rows are never stored)
+      nrt = RT;
       mfma_rows_split<NPW, 2, HG_SPLIT_DEPTH>(planes, pstride, wsplit, sp, NT, lane, bq, acc, dbg);
     } else if (nrt == 2) {
       mfma_rows_split<NPW, 2, HG_SPLIT_DEPTH>(planes, pstride, wsplit, sp, NT, lane, bq, acc, dbg);
@@ -882,7 +883,7 @@ __device__ __forceinline__ void panel_times_wt_split(float *t, int pstride, int 
   __syncthreads();
   HG_STAMP(10);
   const int q = F_out >> 2;  // float4 pieces per row
-  for (int i = tid; i < nrows * q; i += BS) {
+  for (int i = tid; i < nrows * q; i += 256) {
     const int r = i / q, c = (i - r * q) * 4;
     float4 o = *reinterpret_cast<const float4 *>(t + r * LD + c);
     if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
@@ -1218,7 +1219,7 @@ __host__ __device__ inline int lin_tile_floats(int cap, int rows_cap, int tw) {
 // SPLIT (LIN, !LINW, K = 128 only): the matrix phase as six bf16 products per fp32 product (mfma_rows_split); a.epi.wsplit.
 template <int LPR, int VEC, int U, bool FAST, bool MAT, bool SCALED, bool DBG, bool LIN = false, int BS = 256, bool LINW = true, bool SPLIT = false>
 __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW ? (LPR >= 32 ? HG_LIN_WAVES_STAGED32 : HG_LIN_WAVES_STAGED) : LPR >= 32 ? HG_LIN_WAVES32 : LPR == 16 ? HG_LIN_WAVES16 : HG_LIN_WAVES8) : 1, 8))) void fused_packed_kernel(const FusedArgs a) {
-  static_assert(!LIN || BS == 256 || (SPLIT && BS == 512), "the linear epilogue is written for four waves (bf16x6 form: four or eight)");
+  static_assert(!LIN || BS == 256, "the linear epilogue is written for four waves");
   static_assert(!SPLIT || (LIN && !LINW && LPR == 32 && VEC == 4), "bf16x6 matrix phase: K = 128 staged instances");
   constexpr int NG = BS / LPR;
   constexpr int TW = LPR * VEC;
@@ -1428,7 +1429,7 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
     // follow (issued before hop 2 they would hold K/4 more registers through it: 78 instead of 64 VGPRs)
     [[maybe_unused]] float bv[BPre<TW / 4>::N];
     [[maybe_unused]] SplitB bsp[HG_SPLIT_DEPTH];
-    const LinSplit sp = lin_split(tid >> 6, a.F_out >> 4, BS / 64);
+    const LinSplit sp = lin_split(tid >> 6, a.F_out >> 4);
     if constexpr (SPLIT) {  // the first steps' B fragments (three bf16 planes each): in flight during hop 2
       if (sp.active) {
 #pragma unroll
@@ -1477,8 +1478,8 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
       __syncthreads();
       HG_STAMP(6);
       HG_STAMP(7);
-      if (a.F_out > 64) panel_times_wt_split<2, BS>(tile, pstride, nrows, a.F_out, static_cast<const uint4 *>(a.epi.wsplit), prow, a.Y, tid, bsp, a.epi.relu, stp, DBG ? a.debug : 0);
-      else panel_times_wt_split<1, BS>(tile, pstride, nrows, a.F_out, static_cast<const uint4 *>(a.epi.wsplit), prow, a.Y, tid, bsp, a.epi.relu, stp, DBG ? a.debug : 0);
+      if (a.F_out > 64) panel_times_wt_split<2>(tile, pstride, nrows, a.F_out, static_cast<const uint4 *>(a.epi.wsplit), prow, a.Y, tid, bsp, a.epi.relu, stp, DBG ? a.debug : 0);
+      else panel_times_wt_split<1>(tile, pstride, nrows, a.F_out, static_cast<const uint4 *>(a.epi.wsplit), prow, a.Y, tid, bsp, a.epi.relu, stp, DBG ? a.debug : 0);
       HG_STAMP_FLUSH();
       return;
     }
@@ -2160,28 +2161,6 @@ static hipError_t launch_fused_t(const FusedArgs &a, hipStream_t stream) {
       return launch_lds<fused_packed_kernel<LPR, VEC, 8, true, false, false, false, false, 1024>, 1024>(grid, lds, stream, a);
     }
   }
-#ifdef HG_TUNING
-  if constexpr (VEC == 4 && LPR == 32) {
-    // experiment (HG_LIN_PANEL512): the bf16x6 epilogue on 512-thread panels of 64 rows / 96 slots
-    if (a.ng == 512 / LPR && a.Wlin && a.epi.wsplit) {
-      const bool fast = a.x_bytes > 0 && a.nrows_x < (1 << 24) && (!a.Xe_mat || (a.mat_bytes > 0 && a.nrows_mat < (1 << 24)));
-      const int ps = split_plane_bytes(a.rows_cap);
-      if (!fast || a.F != TW || a.rows_cap > 64 || (a.F_out & 15) || a.F_out > TW || 3 * ps > a.cap * TW * 4) return hipErrorInvalidValue;
-      FusedArgs ad = a;
-      ad.debug = 0;
-      ad.dv_regs = 0;
-      const dim3 grid(a.npanels, 1);
-      const size_t lds = (size_t)lin_tile_floats(a.cap, a.rows_cap, TW) * 4 + (size_t)a.max_rec_words * 4 + fused_scale_floats(ad) * 4 + 16;
-      const int spec = (a.Xe_mat ? 1 : 0) | ((a.degE || a.W) ? 2 : 0);
-      switch (spec) {
-        case 0: return launch_lds<fused_packed_kernel<LPR, VEC, HG_LIN_U32, true, false, false, false, true, 512, false, true>, 512>(grid, lds, stream, ad);
-        case 1: return launch_lds<fused_packed_kernel<LPR, VEC, HG_LIN_U32, true, true, false, false, true, 512, false, true>, 512>(grid, lds, stream, ad);
-        case 2: return launch_lds<fused_packed_kernel<LPR, VEC, HG_LIN_U32, true, false, true, false, true, 512, false, true>, 512>(grid, lds, stream, ad);
-        default: return launch_lds<fused_packed_kernel<LPR, VEC, HG_LIN_U32, true, true, true, false, true, 512, false, true>, 512>(grid, lds, stream, ad);
-      }
-    }
-  }
-#endif
   if (a.ng != 256 / LPR) return hipErrorInvalidValue;  // records were packed for another lane layout
   const int col_tiles = (a.F + TW - 1) / TW;
   const Tuning &t = tuning();
@@ -2367,8 +2346,7 @@ bool fused_linear_ok(const FusedArgs &a) {
   return (a.F == 32 || a.F == 64 || a.F == 128) && a.F_out > 0 && (a.F_out & 15) == 0 && t.fused_fast &&
          !(t.fused_debug & 222) && a.x_bytes > 0 && a.nrows_x < (1 << 24) &&
          (!a.Xe_mat || (a.mat_bytes > 0 && a.nrows_mat < (1 << 24))) &&
-         ((a.ng == 256 / lpr && a.rows_cap <= 4 * (256 / lpr)) || (a.epi.wsplit && a.ng == 512 / lpr && a.rows_cap <= 4 * (512 / lpr))) &&
-         a.rows_cap <= a.cap;
+         a.ng == 256 / lpr && a.rows_cap <= 4 * (256 / lpr) && a.rows_cap <= a.cap;
 }
 
 hipError_t launch_linear(const LinearArgs &a, hipStream_t stream) {
