@@ -1686,6 +1686,69 @@ def test_random_graphs_widths_and_options_differential(hg, oracle, seed):
                     (seed, inc.name, F, variant, weighted)
 
 
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("HG_FUZZ_SEEDS_LIN", "6")))))  # a soak run sets it higher
+def test_bf16x6_epilogue_differential(hg, oracle, seed):
+    """Differential sweep of the folded layer at F_in = 128 in both forms of the matrix phase (fp32 MFMA / bf16x6): per seed a
+    random hypergraph family beyond 2^18 incidences (uniform ragged with empty hyperedges, a block-diagonal batch, mid-sized
+    hyperedges that are partly materialised, duplicate incidences), a random output width, features and weights of random scale
+    (2^-20 .. 2^20: the bf16 split keeps fp32's exponent), weighted or not, with or without residual / relu -- against float64
+    at 1e-6 x the mass of each element's terms, the two forms' T_out bit for bit, and the six-product form never worse than
+    1.5 x the fp32 form."""
+    from hypergef_amd.plan import Plan
+    rng = np.random.default_rng(7000 + seed)
+    kind = seed % 4
+    if kind == 0:
+        inc = synth.random_incidence(int(rng.integers(60000, 120000)), int(rng.integers(120000, 180000)), float(rng.uniform(3, 8)),
+                                     seed=seed, empty_frac=float(rng.uniform(0, 0.2)))
+    elif kind == 1:
+        inc = synth.replicate_block_diagonal(synth.pubmed_shape(seed=seed), int(rng.integers(8, 14)))
+    elif kind == 2:
+        inc = synth.random_incidence(int(rng.integers(30000, 60000)), int(rng.integers(20000, 30000)), float(rng.uniform(18, 40)),
+                                     seed=seed, max_size=200)
+    else:
+        inc = synth.replicate_block_diagonal(synth.citeseer_shape(seed=seed), int(rng.integers(80, 120)))
+        reps = np.where(rng.random(inc.nnz) < 0.03, 2, 1)
+        eid = np.repeat(np.arange(inc.M), np.diff(inc.csrptr))
+        cnt = np.zeros(inc.M + 1, np.int64)
+        np.add.at(cnt, eid + 1, reps)
+        inc = synth.Incidence(inc.N, inc.M, np.cumsum(cnt).astype(np.int32), np.repeat(inc.colind, reps).astype(np.int32),
+                              name=inc.name + "+dups")
+    assert inc.nnz > 1 << 18
+    F = 128
+    F_out = int(rng.choice([16, 32, 48, 64, 80, 96, 112, 128]))
+    xs, ws = 2.0 ** float(rng.integers(-20, 21)), 2.0 ** float(rng.integers(-6, 7))
+    X = (rng.standard_normal((inc.N, F)) * xs).astype(np.float32)
+    Wl = (rng.standard_normal((F_out, F)) * ws / np.sqrt(F)).astype(np.float32)
+    degE, degV = oracle.degrees(inc.N, inc.M, inc.csrptr, inc.colind)
+    degE = np.where(np.isinf(degE), 0, degE).astype(np.float32)
+    W = (rng.random(inc.M) + 0.5).astype(np.float32)
+    weighted, layer = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    ptr, ind = _dev(inc.csrptr), _dev(inc.colind)
+    plan = Plan.from_tensors(inc.N, ptr, ind)
+    sc = (_dev(degE.ravel()), _dev(degV.ravel()), _dev(W)) if weighted else (None, None, None)
+    R = (rng.standard_normal((inc.N, F)) * xs).astype(np.float32) if layer else None
+    ca, cb = (0.9, 0.1) if layer else (1.0, 0.0)
+    f64, mass = _float64_layer(inc, X, Wl, *((degE, degV, W) if weighted else ()))
+    if layer:  # t = ca * Aggr(X) + cb * R before the product
+        f64 = ca * f64 + cb * (R.astype(np.float64) @ Wl.T.astype(np.float64))
+        mass = ca * mass + cb * (np.abs(R).astype(np.float64) @ np.abs(Wl.T).astype(np.float64))
+        f64 = np.maximum(f64, 0)
+    unit = max(float(mass.max()) * 2.0 ** -20, 1e-30)  # "1" of max(1, mass) at this seed's scale: tiny elements get no free pass
+    tol = 1e-6 * np.maximum(unit, mass)
+    errs, T = {}, {}
+    for math in ("f32", "bf16x6"):
+        T[math] = torch.full((inc.N, F), float("nan"), device=DEV)
+        Y = plan.aggregate_linear(ptr, ind, _dev(X), _dev(Wl), *sc, variant="fused", math=math, t_out=T[math],
+                                  residual=None if R is None else _dev(R), ca=ca, cb=cb, relu=layer)
+        y = Y.cpu().numpy().astype(np.float64)
+        assert np.isfinite(y).all(), (seed, math)
+        e = np.abs(y - f64)
+        assert (e <= tol).all(), (seed, inc.name, F_out, math, weighted, layer, xs, ws, int((e > tol).sum()), float((e / tol).max()))
+        errs[math] = float((e / np.maximum(unit, mass)).max())
+    assert torch.equal(T["f32"], T["bf16x6"]), seed
+    assert errs["bf16x6"] <= 1.5 * errs["f32"] + 6e-8, (seed, errs)
+
+
 @pytest.mark.parametrize("dname", ["house-committees", "pubmed", "zoo", "cora"])
 def test_timed_choice_pins_auto_and_keeps_results(hg, oracle, dname):
     """hg_plan_tune_f32 (the reference's HyperGAggr_tune, hgnnAgg.cuh:1115-1157, on this backend's candidates):
