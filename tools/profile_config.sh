@@ -11,7 +11,7 @@ root=$GRAFT_REPO_ROOT; [ -z "$root" ] && root=$(cd $(dirname $0)/.. && pwd)
 out=$root/gpurun_out/prof_$tag; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $root
 common="--no-extras --no-cpu-baseline --no-parity"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/stats -o s --output-format csv -- python3 bench.py --steps 50 --warmup 5 $common "$@" > $out/stats.log 2>&1 || { tail -5 $out/stats.log; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/stats -o s --output-format csv -- python3 bench.py --steps 200 --warmup 20 $common "$@" > $out/stats.log 2>&1 || { tail -5 $out/stats.log; exit 1; }
 cp $out/stats/s_kernel_stats.csv $out/${tag}_kernel_stats.csv
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/pmc_fetch -o f --output-format csv -- python3 bench.py --steps 3 --warmup 1 $common "$@" > $out/pmc_fetch.log 2>&1 || { tail -5 $out/pmc_fetch.log; exit 1; }
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace -d $out/pmc_write -o w --output-format csv -- python3 bench.py --steps 3 --warmup 1 $common "$@" > $out/pmc_write.log 2>&1 || { tail -5 $out/pmc_write.log; exit 1; }
