@@ -4,7 +4,7 @@
 # one traffic.json.  usage (GPU box): tools/collect_r04.sh
 root=$GRAFT_REPO_ROOT; [ -z "$root" ] && root=$(cd $(dirname $0)/.. && pwd)
 cd $root; out=gpurun_out/r04; mkdir -p $out
-timeout -k 10 600 python3 bench.py > $out/bench_default.log 2>&1 || { tail -5 $out/bench_default.log; exit 1; }
+timeout -k 10 600 python3 bench.py --detail $out/r04_bench_detail.json > $out/bench_default.log 2>&1 || { tail -5 $out/bench_default.log; exit 1; }
 tail -1 $out/bench_default.log > $out/r04_bench_default.json
 run() { tag=$1; shift; tools/profile_config.sh $tag "$@" > $out/prof_$tag.log 2>&1 || { echo "profile $tag failed"; tail -3 $out/prof_$tag.log; return; }
         cp gpurun_out/prof_$tag/${tag}_kernel_stats.csv $out/r04_${tag}_kernel_stats.csv
