@@ -1032,7 +1032,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KSTEPS >= 3
 // all TA x TB output tiles in accumulators; waves are reduced through LDS in wave order,
 // workgroups through one partial matrix each and a second kernel (fixed order: deterministic).
 template <int TA, int TB>
-__global__ __launch_bounds__(256) void wgrad_kernel(const float *A, const float *B, float *partial, int64_t N,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TA * TB >= 16 ? 3 : TA * TB >= 8 ? 4 : 1, 8))) void wgrad_kernel(const float *A, const float *B, float *partial, int64_t N,
                                                     int64_t rows_per_wg, int lda, int ldb, int nbb, int nblocks, int nparts) {
   constexpr int FA = TA * 16, FB = TB * 16;
   // A wider product (lda, ldb = the operands' row strides) runs as nblocks independent FA x FB blocks of C over the same rows.
@@ -1064,9 +1064,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *A, const float 
   // and feeds the i-th of them to tile i: tile i then stands for the columns {TA c + i}, a permutation of the output's rows
   // (columns for B) that the reduction below undoes.  Sixteen lanes read one whole 4 TA-float segment of a row per
   // instruction; with tile i = columns 16 i .. 16 i + 15 (round 1) every row was fetched as TA separate 64-byte pieces.
+  // Every load is issued unconditionally and unmasked, from a row clamped into the wave's range; only the last, partial step of
+  // a range (N not a multiple of four) zeroes the rows past the end, after the loop.  With the loads under `if (row < r1)`
+  // branches the compiler could not count them and put s_waitcnt vmcnt(0) in front of every step's MFMAs -- each step then
+  // waited for the loads it had just issued, the whole HBM latency per four rows (the kernel ran at half the rate its matrix
+  // pipe allows); a select on the loaded value has the same effect (it consumes the value at once).
   auto load = [&](int64_t n, float (&a)[TA], float (&b)[TB]) {
-    const int64_t row = n + kk;
-    const bool ok = row < r1;
+    const int64_t row = min(n + kk, r1 - 1);  // r1 > r0 >= 0 where this is called
     typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
     typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
     auto fetch = [&](const float *p, auto &dst, auto nt) {
@@ -1074,39 +1078,70 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float *A, const float 
       if constexpr (T % 4 == 0) {
 #pragma unroll
         for (int q = 0; q < T / 4; q++) {
-          const f4u v = ok ? *reinterpret_cast<const f4u *>(p + 4 * q) : f4u{0.f, 0.f, 0.f, 0.f};
+          const f4u v = *reinterpret_cast<const f4u *>(p + 4 * q);
           dst[4 * q] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
         }
       } else if constexpr (T == 2) {
-        const f2u v = ok ? *reinterpret_cast<const f2u *>(p) : f2u{0.f, 0.f};
+        const f2u v = *reinterpret_cast<const f2u *>(p);
         dst[0] = v.x; dst[1] = v.y;
       } else {
 #pragma unroll
-        for (int q = 0; q < T; q++) dst[q] = ok ? p[q] : 0.f;
+        for (int q = 0; q < T; q++) dst[q] = p[q];
       }
     };
     fetch(A + row * lda + c * TA, a, std::integral_constant<int, TA>{});
     fetch(B + row * ldb + c * TB, b, std::integral_constant<int, TB>{});
   };
-  float a2[TA], b2[TB];
-  if (r0 < r1) load(r0, a0, b0);
-  if (r0 + 4 < r1) load(r0 + 4, a1, b1);
-  for (int64_t n = r0; n < r1; n += 4) {
-    if (n + 8 < r1) load(n + 8, a2, b2);  // two steps (eight rows) in flight behind this step's MFMAs
+  auto step = [&](const float (&a)[TA], const float (&b)[TB]) {
 #pragma unroll
     for (int i = 0; i < TA; i++)
 #pragma unroll
       for (int j = 0; j < TB; j++)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < TA; i++) {
-      a0[i] = a1[i];
-      a1[i] = a2[i];
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+  };
+  // Three operand buffers in rotation, the loop unrolled by three so that the rotation is a renaming: with register moves
+  // (a0 = a1, a1 = a2) the move out of the buffer just loaded waited for that load at the end of every step.
+  float a2[TA], b2[TB];
+  if (r0 < r1) {
+    const int64_t rfull = r0 + ((r1 - r0) & ~(int64_t)3);  // whole steps of four rows
+    load(r0, a0, b0);
+    load(r0 + 4, a1, b1);
+    int64_t n = r0;
+    for (; n + 12 <= rfull; n += 12) {  // two steps (eight rows) in flight behind every step's MFMAs
+      // (scheduling barriers: left alone the compiler sinks a step's loads behind the wait for the step before)
+      load(n + 8, a2, b2);
+      __builtin_amdgcn_sched_barrier(0);
+      step(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      load(n + 12, a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      step(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      load(n + 16, a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      step(a2, b2);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    // zero to two whole steps and the range's last one to three rows (clamped duplicates beside them: zeroed here)
+    auto tail = [&](float (&a)[TA], float (&b)[TB], int64_t at) {
+      if (at >= r1) return;
+      const bool ok = at + kk < r1;
 #pragma unroll
-    for (int j = 0; j < TB; j++) {
-      b0[j] = b1[j];
-      b1[j] = b2[j];
+      for (int i = 0; i < TA; i++) a[i] = ok ? a[i] : 0.f;
+#pragma unroll
+      for (int j = 0; j < TB; j++) b[j] = ok ? b[j] : 0.f;
+      step(a, b);
+    };
+    if (n + 8 <= rfull) {
+      load(n + 8, a2, b2);
+      step(a0, b0);
+      step(a1, b1);
+      tail(a2, b2, n + 8);
+    } else if (n + 4 <= rfull) {
+      step(a0, b0);
+      tail(a1, b1, n + 4);
+    } else {
+      tail(a0, b0, n);
     }
   }
   // D layout: register q of tile (i, j) is tile row 4 (lane >> 4) + q, tile column lane & 15, i.e. (the load's permutation)
