@@ -997,18 +997,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KSTEPS >= 3
   }
   if (a.epi.R || a.epi.ca != 1.f || a.epi.T_out) {  // t' = ca * t + cb * R[row]
     const float cb = a.epi.cb_dev ? *a.epi.cb_dev : a.epi.cb;  // uniform: one scalar load
+    // row ids, then the rows of R, each set in flight together and unconditionally (a row past the end reads the block's last
+    // one): inside the `r < nrows` branch below every load was followed by s_waitcnt vmcnt(0) -- 2 NL dependent round trips
+    int64_t grow[NL];
+    float4 rr[NL];
+#pragma unroll
+    for (int j = 0; j < NL; j++) grow[j] = row0 + min((threadIdx.x + j * 256) / (K / 4), nrows - 1);
+    if (a.rowmap) {
+      int32_t m[NL];
+#pragma unroll
+      for (int j = 0; j < NL; j++) m[j] = a.rowmap[grow[j]];
+#pragma unroll
+      for (int j = 0; j < NL; j++) grow[j] = m[j];
+    }
+    if (a.epi.R) {
+#pragma unroll
+      for (int j = 0; j < NL; j++)
+        rr[j] = *reinterpret_cast<const float4 *>(a.epi.R + grow[j] * K + ((threadIdx.x + j * 256) % (K / 4)) * 4);
+    }
 #pragma unroll
     for (int j = 0; j < NL; j++) {
       const int i = threadIdx.x + j * 256, r = i / (K / 4), c = (i % (K / 4)) * 4;
       if (r >= nrows) continue;
-      const int64_t grow = a.rowmap ? (int64_t)a.rowmap[row0 + r] : row0 + r;
       float4 t4 = v[j];
       t4 = make_float4(t4.x * a.epi.ca, t4.y * a.epi.ca, t4.z * a.epi.ca, t4.w * a.epi.ca);
-      if (a.epi.R) {
-        const float4 rr = *reinterpret_cast<const float4 *>(a.epi.R + grow * K + c);
-        t4 = make_float4(t4.x + rr.x * cb, t4.y + rr.y * cb, t4.z + rr.z * cb, t4.w + rr.w * cb);
-      }
-      if (a.epi.T_out) *reinterpret_cast<float4 *>(a.epi.T_out + grow * K + c) = t4;
+      if (a.epi.R) t4 = make_float4(t4.x + rr[j].x * cb, t4.y + rr[j].y * cb, t4.z + rr[j].z * cb, t4.w + rr[j].w * cb);
+      if (a.epi.T_out) *reinterpret_cast<float4 *>(a.epi.T_out + grow[j] * K + c) = t4;
       v[j] = t4;
     }
   }
@@ -1218,6 +1232,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *partial,
 #ifndef HG_LIN_MERGE_PHASES
 #define HG_LIN_MERGE_PHASES 1  // K = 128 staged epilogue instances: hop 1's two phases as one run of batches (with twelve gathers in
                                // flight at the six-wave budget: -1.2 % on pubmed x64 128 -> 128, -2.2 % on 128 -> 64, same box, three rounds)
+#endif
+#ifndef HG_LIN_R_EARLY
+#define HG_LIN_R_EARLY 1  // a layer's residual rows are requested before hop 2 (0: after it, all four together)
 #endif
 #ifndef HG_LIN_U32
 #define HG_LIN_U32 12  // row gathers in flight per lane, K = 128 staged instances
@@ -1474,6 +1491,17 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
     }
     const int rpg = (nrows + NG - 1) / NG;  // <= 4 (launcher)
     const int r0 = min(g * rpg, nrows), r1 = min(r0 + rpg, nrows);
+    // A layer's residual rows (t = ca Aggr(X) + cb R): the lane group's four rows of R in flight together, unconditionally (a row
+    // past the group's range reads the panel's last row and is not used), and BEFORE hop 2, which they overlap.  Under
+    // `if (r0 + i < r1)` after hop 2 each load was followed by s_waitcnt vmcnt(0) -- four dependent trips to HBM per panel in every
+    // UniGCNII / UniGIN layer.
+    [[maybe_unused]] V rr[4];
+    if constexpr (HG_LIN_R_EARLY) {
+      if (a.epi.R) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) rr[i] = V::load(a.epi.R + (int64_t)prow[min(r0 + i, nrows - 1)] * F + col);
+      }
+    }
     V outr[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -1487,14 +1515,19 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
     }
     if (a.epi.R || a.epi.ca != 1.f) {  // t' = ca * t + cb * R[v]  (workgroup-uniform)
       const float cb = a.epi.cb_dev ? *a.epi.cb_dev : a.epi.cb;
+      if constexpr (!HG_LIN_R_EARLY) {
+        if (a.epi.R) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) rr[i] = V::load(a.epi.R + (int64_t)prow[min(r0 + i, nrows - 1)] * F + col);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 4; i++)
         if (r0 + i < r1) {
           outr[i].mul(a.epi.ca);
           if (a.epi.R) {
-            V rr = V::load(a.epi.R + (int64_t)prow[r0 + i] * F + col);
-            rr.mul(cb);
-            outr[i].add(rr);
+            rr[i].mul(cb);
+            outr[i].add(rr[i]);
           }
         }
     }

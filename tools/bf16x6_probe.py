@@ -50,8 +50,12 @@ for shape, reps, F, Fo in CASES:
     ws = torch.empty(max(int(_lib.lib().hg_aggr_linear_workspace_bytes(plan._h, F)), 256), dtype=torch.uint8, device=dev)
     T = torch.empty((inc.N, F), dtype=torch.float32, device=dev)
 
+    RES = os.environ.get("PROBE_RES") == "1"  # a whole layer: t = 0.9 Aggr(X) + 0.1 R, relu (timing; the float64 columns then do not apply)
+    R = torch.randn(inc.N, F, device=dev) if RES else None
+
     def run(m, t_out=None):
-        plan.aggregate_linear(ptr, ind, X, weight, variant="fused", out=Y[m], workspace=ws, packed=packed, math=m, t_out=t_out)
+        plan.aggregate_linear(ptr, ind, X, weight, variant="fused", out=Y[m], workspace=ws, packed=packed, math=m, t_out=t_out,
+                              residual=R, ca=0.9 if RES else 1.0, cb=0.1 if RES else 0.0, relu=RES)
 
     ms = {"f32": [], "bf16x6": []}
     for _ in range(rounds):
