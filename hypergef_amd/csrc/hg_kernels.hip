@@ -1327,14 +1327,37 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
     }
   }
 
-  // records are padded to whole 16-byte units: one dwordx4 per lane copies 4 KB per pass
-  for (int i = tid; i < (rt.len >> 2); i += BS)
-    reinterpret_cast<hg_i4 *>(rec)[i] = HG_REC_NT ? __builtin_nontemporal_load(reinterpret_cast<const hg_i4 *>(grec) + i)
-                                                  : reinterpret_cast<const hg_i4 *>(grec)[i];
-  // The scale gathers start from the ids in global memory, in the same round trip as the
-  // record copy (the descriptor says where they are), not after it.
+  // Staging of the record and of the call's scales.  Everything a thread stages first -- its 16 bytes of the record (records are
+  // padded to whole 16-byte units: one dwordx4 per lane copies 4 KB per pass), its slot's bound degE / W factors, its row's
+  // bound degV -- is REQUESTED before anything is written to LDS, from indices clamped into range so that no load sits under a
+  // lane-dependent branch: written as one loop after the other, each loop's load was followed by s_waitcnt vmcnt(0) and its LDS
+  // write, i.e. up to four dependent round trips to memory (record, degE, W, degV) before a weighted panel's first barrier where
+  // one suffices.  The loops below take what is left (records beyond 4 KB, unbound scales: an id first, then the factor).
+  // An unweighted call has one thing to stage and keeps its plain loop (the clamped form cost the pubmed-shape F = 128 batch 4 %).
+  const int nrec4 = rt.len >> 2;  // >= 1: a record has its header
+  const hg_i4 *grec4 = reinterpret_cast<const hg_i4 *>(grec);
+  const bool bound_e = SCALED && a.bsA && (a.degE || a.W) && rt.nslots > 0, bound_v = a.degV && !dv_regs && a.bsD && rt.nrows > 0;
+  const bool pre = bound_e || bound_v;  // workgroup-uniform
+  if (pre) {
+    const hg_i4 rv = HG_REC_NT ? __builtin_nontemporal_load(grec4 + min(tid, nrec4 - 1)) : grec4[min(tid, nrec4 - 1)];
+    float va = 1.f, vb = 1.f, vd = 1.f;
+    if (bound_e) {
+      const int64_t si = rt.slot_base + min(tid, rt.nslots - 1);
+      if (a.degE) va = a.bsA[si];
+      if (a.W) vb = a.bsB[si];
+    }
+    if (bound_v) vd = a.bsD[rt.row_base + min(tid, rt.nrows - 1)];
+    if (tid < nrec4) reinterpret_cast<hg_i4 *>(rec)[tid] = rv;
+    if (bound_e && tid < rt.nslots) {
+      if (a.degE) sA[tid] = va;
+      if (a.W) sB[tid] = vb;
+    }
+    if (bound_v && tid < rt.nrows) sdeg[tid] = vd;
+  }
+  for (int i = pre ? tid + BS : tid; i < nrec4; i += BS)
+    reinterpret_cast<hg_i4 *>(rec)[i] = HG_REC_NT ? __builtin_nontemporal_load(grec4 + i) : grec4[i];
   if (a.degE || a.W)
-    for (int i = tid; i < rt.nslots; i += BS) {
+    for (int i = bound_e ? tid + BS : tid; i < rt.nslots; i += BS) {
       if (a.bsA) {  // bound: one coalesced read instead of a scattered 4-byte gather per slot
         if (a.degE) sA[i] = a.bsA[rt.slot_base + i];
         if (a.W) sB[i] = a.bsB[rt.slot_base + i];
@@ -1345,7 +1368,7 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(LIN ? (!LINW
       }
     }
   if (a.degV && !dv_regs)
-    for (int i = tid; i < rt.nrows; i += BS) {
+    for (int i = bound_v ? tid + BS : tid; i < rt.nrows; i += BS) {
       if (a.bsD) {
         sdeg[i] = a.bsD[rt.row_base + i];
       } else {
