@@ -1878,11 +1878,29 @@ __global__ __launch_bounds__(256) void stream_rows_kernel(const StreamArgs a) {
   int32_t *rec = smem;                                           // [max_rec_words]
   float *sA = reinterpret_cast<float *>(rec + a.max_rec_words);  // [cap]
   float *sB = sA + a.cap;                                        // [cap]
-  for (int i = tid; i < (rt.len >> 2); i += BS)
+  // A scaled call stages the record, then per slot an id and the factors it names: written as loops one after the other that was
+  // four dependent round trips (record, id, scaleA, scaleB) before the barrier.  A thread's piece of the record and its slot's id
+  // are requested together (clamped indices, no lane-dependent branch around a load), then both factors together.
+  const int nrec4 = rt.len >> 2;
+  const bool scaled = (a.scaleA || a.scaleB) && rt.nslots > 0;  // workgroup-uniform
+  if (scaled) {
+    const hg_i4 rv = reinterpret_cast<const hg_i4 *>(grec)[min(tid, nrec4 - 1)];
+    const int si = grec[rt.off_sidx + min(tid, rt.nslots - 1)];  // -1: a chunk (scaled by its fixup) or an empty row (stays exactly 0)
+    const int sc = max(si, 0);
+    float fa = 1.f, fb = 1.f;
+    if (a.scaleA) fa = a.scaleA[sc];
+    if (a.scaleB) fb = a.scaleB[sc];
+    if (tid < nrec4) reinterpret_cast<hg_i4 *>(rec)[tid] = rv;
+    if (tid < rt.nslots) {
+      sA[tid] = si >= 0 ? fa : 1.f;
+      sB[tid] = si >= 0 ? fb : 1.f;
+    }
+  }
+  for (int i = scaled ? tid + BS : tid; i < nrec4; i += BS)
     reinterpret_cast<hg_i4 *>(rec)[i] = reinterpret_cast<const hg_i4 *>(grec)[i];
   if (a.scaleA || a.scaleB)
-    for (int i = tid; i < rt.nslots; i += BS) {
-      const int si = grec[rt.off_sidx + i];  // -1: a chunk (scaled by its fixup) or an empty row (stays exactly 0)
+    for (int i = tid + BS; i < rt.nslots; i += BS) {
+      const int si = grec[rt.off_sidx + i];
       sA[i] = (a.scaleA && si >= 0) ? a.scaleA[si] : 1.f;
       sB[i] = (a.scaleB && si >= 0) ? a.scaleB[si] : 1.f;
     }
