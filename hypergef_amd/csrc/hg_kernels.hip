@@ -1827,11 +1827,13 @@ __global__ __launch_bounds__(1024) void hub_pass_kernel(const HubArgs a) {
     HG_STAMP(5);
     cur ^= 1;
   }
+  int vs0[R];  // the lane group's R partial slots: requested together (read one by one next to their stores they were R dependent
+               // round trips at the end of every workgroup)
 #pragma unroll
-  for (int i = 0; i < R; i++) {
-    const int s0 = a.vslot0[g * R + i];
-    if (s0 >= 0 && col_ok) acc[i].store(a.partial + (int64_t)(s0 + w) * F + col);
-  }
+  for (int i = 0; i < R; i++) vs0[i] = a.vslot0[g * R + i];
+#pragma unroll
+  for (int i = 0; i < R; i++)
+    if (vs0[i] >= 0 && col_ok) acc[i].store(a.partial + (int64_t)(vs0[i] + w) * F + col);
   if constexpr (HEAVY) {  // the lane groups' shares of each heavy hub, added in group order
     for (int h = 0; h < a.n_heavy; h++) {
       V mine = V::zero();
