@@ -1181,15 +1181,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TA * TB >= 
 // out[c * n + i] = sum over parts p = c, c + nchunks, c + 2 nchunks, ... of partial[p * n + i]
 // (blockIdx.y = c).  Run twice -- nparts -> 32 chunks -> 1 -- so that the sum over a thousand
 // partial matrices is spread over 512 workgroups instead of sixteen.
-// fb > 0 (last level of a blocked product): element i of the fb-column block goes to out[(i / fb) * ldc + i % fb].
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *partial, int nparts, int n, float *out, int fb, int ldc) {
+// blockIdx.z = block of a blocked product (its partials follow the previous block's; nbb blocks per block row of C).
+// fb > 0 (last level): element i of block z goes to out[((z / nbb) * fa + i / fb) * ldc + (z % nbb) * fb + i % fb]; else to the
+// block's own run of nchunks * n second-level partials.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *partial, int nparts, int n, float *out, int fa, int fb, int ldc, int nbb) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const int c = blockIdx.y, nchunks = gridDim.y;
+  const int c = blockIdx.y, nchunks = gridDim.y, z = blockIdx.z;
+  partial += (int64_t)z * nparts * n;
   float s = 0.f;
   for (int p = c; p < nparts; p += nchunks) s += partial[(int64_t)p * n + i];
-  if (fb > 0) out[(int64_t)(i / fb) * ldc + (i % fb)] = s;
-  else out[(int64_t)c * n + i] = s;
+  if (fb > 0) out[(int64_t)((z / nbb) * fa + i / fb) * ldc + (z % nbb) * fb + (i % fb)] = s;
+  else out[((int64_t)z * nchunks + c) * n + i] = s;
 }
 
 // Packed form of the fused panel kernel.  The plan hands every panel over as ONE
@@ -2437,16 +2440,12 @@ hipError_t launch_wgrad(int64_t nrows, int32_t Fa, int32_t Fb, const float *A, c
   const int n = Ba * Bb;
   const int mid = nparts > 64 ? 32 : 1;  // second-level partials live behind the first-level ones
   float *p2 = partial + (int64_t)nblocks * nparts * n;
-  for (int b = 0; b < nblocks; b++) {  // fixed order of additions per element: deterministic
-    const float *pb = partial + (int64_t)b * nparts * n;
-    float *cb = C + (int64_t)(b / nbb) * Ba * Fb + (b % nbb) * Bb;
-    if (mid > 1) {
-      float *q = p2 + (int64_t)b * mid * n;
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 255) / 256, mid), dim3(256), 0, stream, pb, nparts, n, q, 0, 0);
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 255) / 256, 1), dim3(256), 0, stream, q, mid, n, cb, Bb, Fb);
-    } else {
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 255) / 256, 1), dim3(256), 0, stream, pb, nparts, n, cb, Bb, Fb);
-    }
+  // every block in the same two launches (blockIdx.z); per element the additions keep their fixed order: deterministic
+  if (mid > 1) {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 255) / 256, mid, nblocks), dim3(256), 0, stream, partial, nparts, n, p2, 0, 0, 0, nbb);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 255) / 256, 1, nblocks), dim3(256), 0, stream, p2, mid, n, C, Ba, Bb, Fb, nbb);
+  } else {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 255) / 256, 1, nblocks), dim3(256), 0, stream, partial, nparts, n, C, Ba, Bb, Fb, nbb);
   }
   return hipGetLastError();
 }
