@@ -342,7 +342,7 @@ def run_config(shape, replicas, F, weighted, variant, steps, warmup, dev, sync, 
         g = torch.Generator().manual_seed(7)
         weight_host = (torch.randn(linear_out, F, generator=g) / F ** 0.5).numpy()
         weight = torch.from_numpy(weight_host).to(dev)
-        packed = planmod.pack_linear(weight)
+        packed = planmod.pack_linear(weight, bf16x6=linear_math == "bf16x6")
         Y = torch.empty((inc.N, linear_out), dtype=torch.float32, device=dev)
         ws = torch.empty(max(int(_lib.lib().hg_aggr_linear_workspace_bytes(plan._h, F)), 256), dtype=torch.uint8, device=dev)
 

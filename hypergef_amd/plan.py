@@ -245,7 +245,7 @@ class Plan:
             raise ValueError("weight must be [F_out, F_in = %d]" % F_in)
         F_out = weight.shape[0]
         if packed is None:
-            packed = packed_linear_cached(weight)
+            packed = packed_linear_cached(weight, math == "bf16x6")
         elif packed.numel() not in (weight.numel(), _lib.lib().hg_linear_pack_floats(F_out, F_in, LIN_BF16X6)):
             raise ValueError("packed does not belong to this weight")
         if math not in ("f32", "bf16x6"):
@@ -403,19 +403,19 @@ def linear_fusion_pays(F_in, F_out):
 LIN_RELU, LIN_BF16X6 = 1, 2  # include/hg_aggr.h: flags of the linear epilogue
 
 
-def pack_linear(weight):
+def pack_linear(weight, bf16x6=False):
     """nn.Linear.weight [F_out, F_in] -> the MFMA fragment order hg_aggr_linear_f32 reads
-    (hg_linear_pack_ex_f32; one or two tiny kernels).  Re-pack after every weight update.
-    At F_in = 128 the buffer also carries the weight's three bf16 planes (HG_LIN_BF16X6), so one packing serves
-    both forms of the matrix phase (aggregate_linear(..., math=))."""
+    (hg_linear_pack_ex_f32; one tiny kernel, two with the planes).  Re-pack after every weight update.
+    bf16x6: at F_in = 128 the buffer also carries the weight's three bf16 planes (HG_LIN_BF16X6); such a packing serves
+    both forms of the matrix phase (aggregate_linear(..., math=)), one without them the fp32 form only."""
     _check_feat(weight, "weight")
     F_out, F_in = weight.shape
     L = _lib.lib()
-    wfrag = torch.empty(max(L.hg_linear_pack_floats(F_out, F_in, LIN_BF16X6), F_out * F_in), dtype=torch.float32,
+    flags = LIN_BF16X6 if bf16x6 else 0
+    wfrag = torch.empty(max(L.hg_linear_pack_floats(F_out, F_in, flags), F_out * F_in), dtype=torch.float32,
                         device=weight.device)
     with torch.cuda.device(weight.device):
-        _lib.check(L.hg_linear_pack_ex_f32(F_out, F_in, _ptr(weight), _ptr(wfrag), LIN_BF16X6,
-                                           _stream_handle(weight.device)))
+        _lib.check(L.hg_linear_pack_ex_f32(F_out, F_in, _ptr(weight), _ptr(wfrag), flags, _stream_handle(weight.device)))
     return wfrag
 
 
@@ -423,11 +423,12 @@ _PACK_CACHE = collections.OrderedDict()
 _PACK_CACHE_MAX = 64
 
 
-def packed_linear_cached(weight):
+def packed_linear_cached(weight, bf16x6=False):
     """pack_linear(weight), kept until the weight is replaced or modified in place (data_ptr /
     torch version counter: an optimizer step bumps it): inference re-uses one packing per layer
     instead of launching the pack kernel on every forward."""
-    key = (weight.data_ptr(), weight._version, tuple(weight.shape), str(weight.device))
+    bf16x6 = bool(bf16x6) and weight.shape[1] == 128  # other widths carry no planes: one entry
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape), str(weight.device), bf16x6)
     stream = torch.cuda.current_stream(weight.device)
     with _CACHE_LOCK:
         hit = _PACK_CACHE.get(key)
@@ -437,7 +438,7 @@ def packed_linear_cached(weight):
         if hit[2] != stream.cuda_stream:  # packed on another stream: order this one behind the pack kernel
             stream.wait_event(hit[3])
         return hit[0]
-    packed = pack_linear(weight)
+    packed = pack_linear(weight, bf16x6)
     with torch.cuda.device(weight.device):
         ev = torch.cuda.Event()
         ev.record(stream)

@@ -45,7 +45,7 @@ for shape, reps, F, Fo in CASES:
     w_host = (torch.randn(Fo, F, generator=g) / F ** 0.5).numpy()
     weight = torch.from_numpy(w_host).to(dev)
     plan = planmod.Plan.from_tensors(inc.N, ptr, ind, planmod.make_opts())
-    packed = planmod.pack_linear(weight)
+    packed = planmod.pack_linear(weight, bf16x6=True)
     Y = {m: torch.empty((inc.N, Fo), dtype=torch.float32, device=dev) for m in ("f32", "bf16x6")}
     ws = torch.empty(max(int(_lib.lib().hg_aggr_linear_workspace_bytes(plan._h, F)), 256), dtype=torch.uint8, device=dev)
     T = torch.empty((inc.N, F), dtype=torch.float32, device=dev)

@@ -18,7 +18,7 @@ plan = planmod.Plan.from_tensors(inc.N, ptr, ind)
 Y = torch.empty(inc.N, F, device=dev)
 L = _lib.lib()
 ws = torch.empty(int(L.hg_aggr_linear_workspace_bytes(plan._h, F)) + 256, dtype=torch.uint8, device=dev)
-wfrag = planmod.pack_linear(Wl)
+wfrag = planmod.pack_linear(Wl, bf16x6=os.environ.get("STAMP_MATH") == "bf16x6")
 buf = (ctypes.c_ulonglong * 16)()
 plain = os.environ.get("STAMP_PLAIN") == "1"  # the plain aggregation's panels instead (phases 0-5, 12 only)
 if plain:
