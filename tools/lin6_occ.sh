@@ -2,6 +2,7 @@
 # bf16x6 epilogue: a seventh workgroup per CU?  Panels of 24 rows / 40 slots (three operand planes of 24 rows = 18 KB inside a
 # 20 KB tile: 22 KB of LDS per workgroup) on a build with the seven-wave register budget and eight gathers in flight
 # (libhgaggr_t7.so: -DHG_LIN_WAVES_STAGED32=7 -DHG_LIN_U32=8), against the shipped 32 rows / 48 slots at six waves, same box.
+# (libhgaggr_tuning.so: make tuning; libhgaggr_t7.so: the same with -DHG_LIN_WAVES_STAGED32=7 -DHG_LIN_U32=8, built by hand)
 # usage (GPU box): tools/lin6_occ.sh
 root=${GRAFT_REPO_ROOT:-$(cd $(dirname $0)/.. && pwd)}; cd $root
 export PROBE_CASES=${PROBE_CASES:-0,2}

@@ -1,6 +1,7 @@
 #!/bin/bash
 # bf16x6 epilogue on 512-thread panels (64 rows / 96 slots, HG_LIN_PANEL512=1, diagnostic build) against the shipped 256-thread
-# panels (32 rows / 48 slots), same box, alternating.  usage (GPU box): tools/lin6_p512.sh
+# panels (32 rows / 48 slots), same box, alternating.  The switch exists in commit 4dd5c20 only (make tuning there); the tree after it carries no
+# 512-thread epilogue.  usage (GPU box): tools/lin6_p512.sh
 root=${GRAFT_REPO_ROOT:-$(cd $(dirname $0)/.. && pwd)}; cd $root
 export PROBE_CASES=${PROBE_CASES:-0,1,2,3} HG_AGGR_LIB=$root/hypergef_amd/lib/libhgaggr_tuning.so
 for round in 1 2 3; do
